@@ -1,0 +1,291 @@
+"""fp32 CPU oracle of the DiT backbone + flow-matching sampler (TEST INFRASTRUCTURE ONLY).
+
+Functional restatement over a plain ``state_dict`` (reference key names, i.e.
+what ``load_checkpoint`` produces after stripping ``ema_model.``:
+F/infer/utils_infer.py:195-209).  Shapes: b batch, n frames, d model dim.
+
+Citations use F/ = /root/reference/src/server/f5_tts/.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+
+import torch
+import torch.nn.functional as F
+
+
+@dataclass(frozen=True)
+class DiTConfig:
+    """model.arch block of F/configs/F5TTS_{Base,Small}_train.yaml:24-30."""
+    dim: int = 1024
+    depth: int = 22
+    heads: int = 16
+    ff_mult: int = 2
+    text_dim: int = 512
+    conv_layers: int = 4
+    mel_dim: int = 100          # F/infer/utils_infer.py:41
+    text_num_embeds: int = 2545  # len(vocab.txt), F/infer/utils_infer.py:240-242
+    dim_head: int = 64          # F/model/backbones/dit.py:100
+
+
+F5_BASE = DiTConfig()
+F5_SMALL = DiTConfig(dim=768, depth=18, heads=12)
+
+
+# ----------------------------------------------------------------------------
+# third-party leaves (restated; "parity unpinned" by the reference)
+# ----------------------------------------------------------------------------
+
+def rotary_freqs(seq_len: int, dim_head: int = 64, base: float = 10000.0) -> torch.Tensor:
+    """x-transformers 2.2.8 RotaryEmbedding.forward_from_seq_len (call site F/model/backbones/dit.py:117,149).
+
+    inv_freq_i = base^(-2i/dim), freqs[n, 2i] = freqs[n, 2i+1] = n * inv_freq_i (interleaved pairs).
+    Returns [1, seq_len, dim_head] fp32; xpos scale is 1.
+    """
+    inv_freq = 1.0 / (base ** (torch.arange(0, dim_head, 2).float() / dim_head))
+    t = torch.arange(seq_len).float()
+    fr = torch.einsum("i,j->ij", t, inv_freq)
+    fr = torch.stack((fr, fr), dim=-1).reshape(seq_len, dim_head)
+    return fr.unsqueeze(0)
+
+
+def rotate_half_interleaved(u: torch.Tensor) -> torch.Tensor:
+    """x-transformers rotate_half: (u0,u1,u2,u3,..) -> (-u1,u0,-u3,u2,..)."""
+    u = u.reshape(*u.shape[:-1], -1, 2)
+    a, b = u.unbind(dim=-1)
+    return torch.stack((-b, a), dim=-1).reshape(*u.shape[:-2], -1)
+
+
+def apply_rotary(t: torch.Tensor, freqs: torch.Tensor) -> torch.Tensor:
+    """x-transformers 2.2.8 apply_rotary_pos_emb with scale=1 (call site F/model/modules.py:418-419).
+
+    Only the first freqs.shape[-1] (=64) channels of the UN-split [b, n, d]
+    tensor are rotated, i.e. head 0 only."""
+    rot = freqs.shape[-1]
+    tr, rest = t[..., :rot], t[..., rot:]
+    tr = tr * freqs.cos() + rotate_half_interleaved(tr) * freqs.sin()
+    return torch.cat((tr, rest), dim=-1)
+
+
+def euler_odeint(fn, y0: torch.Tensor, t: torch.Tensor, keep_trajectory: bool = True):
+    """torchdiffeq 0.2.5 odeint(method='euler') on the fixed grid t (call site F/model/cfm.py:200).
+
+    y_{i+1} = y_i + (t_{i+1} - t_i) * fn(t_i, y_i); fn receives t_i as a 0-dim tensor."""
+    ys = [y0]
+    y = y0
+    for i in range(t.numel() - 1):
+        y = y + (t[i + 1] - t[i]) * fn(t[i], y)
+        if keep_trajectory:
+            ys.append(y)
+    if keep_trajectory:
+        return torch.stack(ys)
+    return y
+
+
+# ----------------------------------------------------------------------------
+# reference-owned math (pinned by tests/golden fixtures)
+# ----------------------------------------------------------------------------
+
+def lens_to_mask(lens: torch.Tensor, length: int | None = None) -> torch.Tensor:
+    """F/model/utils.py:42-47."""
+    if length is None:
+        length = int(lens.amax())
+    return torch.arange(length)[None, :] < lens[:, None]
+
+
+def sinus_time_embed(t: torch.Tensor, dim: int = 256, scale: float = 1000.0) -> torch.Tensor:
+    """F/model/modules.py:154-161: [sin(1000 t f_k) || cos(..)], f_k = exp(-k ln(1e4)/(half-1))."""
+    half = dim // 2
+    f = torch.exp(torch.arange(half).float() * -(math.log(10000) / (half - 1)))
+    e = scale * t[:, None] * f[None, :]
+    return torch.cat((e.sin(), e.cos()), dim=-1)
+
+
+def time_embed(sd, t: torch.Tensor, p="transformer.time_embed.") -> torch.Tensor:
+    """TimestepEmbedding, F/model/modules.py:648-658."""
+    h = sinus_time_embed(t).to(t.dtype)
+    h = F.linear(h, sd[p + "time_mlp.0.weight"], sd[p + "time_mlp.0.bias"])
+    h = F.silu(h)
+    return F.linear(h, sd[p + "time_mlp.2.weight"], sd[p + "time_mlp.2.bias"])
+
+
+def text_pos_table(dim: int, end: int = 4096, theta: float = 10000.0) -> torch.Tensor:
+    """precompute_freqs_cis, F/model/modules.py:196-207: [cos(pos w_j) || sin(pos w_j)]."""
+    w = 1.0 / (theta ** (torch.arange(0, dim, 2)[: dim // 2].float() / dim))
+    ang = torch.outer(torch.arange(end), w).float()
+    return torch.cat([ang.cos(), ang.sin()], dim=-1)
+
+
+def grn(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor) -> torch.Tensor:
+    """GRN, F/model/modules.py:231-234 (L2 norm over the sequence axis, unmasked)."""
+    g = torch.norm(x, p=2, dim=1, keepdim=True)
+    nx = g / (g.mean(dim=-1, keepdim=True) + 1e-6)
+    return gamma * (x * nx) + beta + x
+
+
+def convnext_v2_block(sd, p: str, x: torch.Tensor) -> torch.Tensor:
+    """ConvNeXtV2Block.forward, F/model/modules.py:259-269 (dilation 1, k=7, pad 3)."""
+    dim = x.shape[-1]
+    r = x
+    y = F.conv1d(x.transpose(1, 2), sd[p + "dwconv.weight"], sd[p + "dwconv.bias"], padding=3, groups=dim)
+    y = y.transpose(1, 2)
+    y = F.layer_norm(y, (dim,), sd[p + "norm.weight"], sd[p + "norm.bias"], eps=1e-6)
+    y = F.linear(y, sd[p + "pwconv1.weight"], sd[p + "pwconv1.bias"])
+    y = F.gelu(y)  # erf form (nn.GELU() default, modules.py:255)
+    y = grn(y, sd[p + "grn.gamma"], sd[p + "grn.beta"])
+    y = F.linear(y, sd[p + "pwconv2.weight"], sd[p + "pwconv2.bias"])
+    return r + y
+
+
+def text_embed(sd, cfg: DiTConfig, text: torch.Tensor, seq_len: int, drop_text: bool,
+               p="transformer.text_embed.") -> torch.Tensor:
+    """TextEmbedding.forward, F/model/backbones/dit.py:47-69."""
+    ids = (text + 1)[:, :seq_len]
+    ids = F.pad(ids, (0, seq_len - ids.shape[1]), value=0)
+    if drop_text:
+        ids = torch.zeros_like(ids)
+    e = F.embedding(ids, sd[p + "text_embed.weight"])
+    if cfg.conv_layers > 0:
+        pos = torch.arange(seq_len).clamp(max=4095)  # get_pos_embed_indices, modules.py:210-219
+        e = e + text_pos_table(cfg.text_dim)[pos][None]
+        for i in range(cfg.conv_layers):
+            e = convnext_v2_block(sd, f"{p}text_blocks.{i}.", e)
+    return e
+
+
+def conv_pos_embed(sd, p: str, x: torch.Tensor) -> torch.Tensor:
+    """ConvPositionEmbedding.forward without mask, F/model/modules.py:171-190 (k=31, groups=16)."""
+    y = x.permute(0, 2, 1)
+    y = F.mish(F.conv1d(y, sd[p + "conv1d.0.weight"], sd[p + "conv1d.0.bias"], padding=15, groups=16))
+    y = F.mish(F.conv1d(y, sd[p + "conv1d.2.weight"], sd[p + "conv1d.2.bias"], padding=15, groups=16))
+    return y.permute(0, 2, 1)
+
+
+def input_embed(sd, x, cond, temb, drop_audio_cond: bool, p="transformer.input_embed.") -> torch.Tensor:
+    """InputEmbedding.forward, F/model/backbones/dit.py:81-87."""
+    if drop_audio_cond:
+        cond = torch.zeros_like(cond)
+    h = F.linear(torch.cat((x, cond, temb), dim=-1), sd[p + "proj.weight"], sd[p + "proj.bias"])
+    return conv_pos_embed(sd, p + "conv_pos_embed.", h) + h
+
+
+def attention(sd, p: str, cfg: DiTConfig, x, mask, rope) -> torch.Tensor:
+    """AttnProcessor.__call__, F/model/modules.py:399-449."""
+    b, n, _ = x.shape
+    q = F.linear(x, sd[p + "to_q.weight"], sd[p + "to_q.bias"])
+    k = F.linear(x, sd[p + "to_k.weight"], sd[p + "to_k.bias"])
+    v = F.linear(x, sd[p + "to_v.weight"], sd[p + "to_v.bias"])
+    if rope is not None:
+        q = apply_rotary(q, rope)
+        k = apply_rotary(k, rope)
+    h, dh = cfg.heads, cfg.dim_head
+    q = q.view(b, n, h, dh).transpose(1, 2)
+    k = k.view(b, n, h, dh).transpose(1, 2)
+    v = v.view(b, n, h, dh).transpose(1, 2)
+    am = None
+    if mask is not None:
+        am = mask[:, None, None, :].expand(b, h, n, n)
+    o = F.scaled_dot_product_attention(q, k, v, attn_mask=am, dropout_p=0.0, is_causal=False)
+    o = o.transpose(1, 2).reshape(b, n, h * dh)
+    o = F.linear(o, sd[p + "to_out.0.weight"], sd[p + "to_out.0.bias"])
+    if mask is not None:
+        o = o.masked_fill(~mask[..., None], 0.0)
+    return o
+
+
+def dit_block(sd, p: str, cfg: DiTConfig, x, t, mask, rope) -> torch.Tensor:
+    """DiTBlock.forward + AdaLayerNormZero.forward, F/model/modules.py:558-572, 285-290."""
+    d = cfg.dim
+    m = F.linear(F.silu(t), sd[p + "attn_norm.linear.weight"], sd[p + "attn_norm.linear.bias"])
+    shift_a, scale_a, gate_a, shift_m, scale_m, gate_m = m.chunk(6, dim=1)
+    h = F.layer_norm(x, (d,), eps=1e-6) * (1 + scale_a[:, None]) + shift_a[:, None]
+    a = attention(sd, p + "attn.", cfg, h, mask, rope)
+    x = x + gate_a[:, None] * a
+    h = F.layer_norm(x, (d,), eps=1e-6) * (1 + scale_m[:, None]) + shift_m[:, None]
+    f = F.linear(h, sd[p + "ff.ff.0.0.weight"], sd[p + "ff.ff.0.0.bias"])
+    f = F.gelu(f, approximate="tanh")  # modules.py:556
+    f = F.linear(f, sd[p + "ff.ff.2.weight"], sd[p + "ff.ff.2.bias"])
+    return x + gate_m[:, None] * f
+
+
+def dit_forward(sd, cfg: DiTConfig, x, cond, text, time, drop_audio_cond: bool, drop_text: bool,
+                mask=None) -> torch.Tensor:
+    """DiT.forward, F/model/backbones/dit.py:130-163 (long_skip_connection=False)."""
+    b, n = x.shape[:2]
+    if time.ndim == 0:
+        time = time.repeat(b)
+    t = time_embed(sd, time)
+    te = text_embed(sd, cfg, text, n, drop_text)
+    h = input_embed(sd, x, cond, te, drop_audio_cond)
+    rope = rotary_freqs(n, cfg.dim_head)
+    for i in range(cfg.depth):
+        h = dit_block(sd, f"transformer.transformer_blocks.{i}.", cfg, h, t, mask, rope)
+    s = F.linear(F.silu(t), sd["transformer.norm_out.linear.weight"], sd["transformer.norm_out.linear.bias"])
+    scale, shift = s.chunk(2, dim=1)  # (scale, shift) order: modules.py:308
+    h = F.layer_norm(h, (cfg.dim,), eps=1e-6) * (1 + scale)[:, None, :] + shift[:, None, :]
+    return F.linear(h, sd["transformer.proj_out.weight"], sd["transformer.proj_out.bias"])
+
+
+def sway_time_grid(steps: int, sway_sampling_coef: float | None, dtype=torch.float32) -> torch.Tensor:
+    """F/model/cfm.py:196-198."""
+    t = torch.linspace(0, 1, steps + 1, dtype=dtype)
+    if sway_sampling_coef is not None:
+        t = t + sway_sampling_coef * (torch.cos(torch.pi / 2 * t) - 1 + t)
+    return t
+
+
+def make_noise(durations, mel_dim: int, seed: int | None, y0=None) -> torch.Tensor:
+    """F/model/cfm.py:181-186: per item randn(dur, mel_dim) from the global CPU generator, zero padded."""
+    if y0 is not None:
+        return y0
+    ys = []
+    for dur in durations:
+        if seed is not None:
+            torch.manual_seed(seed)
+        ys.append(torch.randn(int(dur), mel_dim))
+    return torch.nn.utils.rnn.pad_sequence(ys, padding_value=0, batch_first=True)
+
+
+@torch.no_grad()
+def cfm_sample(sd, cfg: DiTConfig, cond: torch.Tensor, text: torch.Tensor, duration, *, lens=None, steps=32,
+               cfg_strength=1.0, sway_sampling_coef=None, seed=None, max_duration=4096, y0=None,
+               edit_mask=None, no_ref_audio=False, forward_fn=None, keep_trajectory=True):
+    """CFM.sample, F/model/cfm.py:82-210, for mel `cond` [b, n, 100] and int `text` [b, nt] (-1 padded).
+
+    `forward_fn` lets a test substitute another backbone (UNetT oracle, or a
+    precision-emulating variant); default is dit_forward.  Returns (out, trajectory)."""
+    fwd = forward_fn or (lambda **kw: dit_forward(sd, cfg, **kw))
+    cond = cond.float()
+    b, cond_len = cond.shape[:2]
+    if lens is None:
+        lens = torch.full((b,), cond_len, dtype=torch.long)
+    text_lens = (text != -1).sum(dim=-1)
+    lens = torch.maximum(text_lens, lens)                                   # cfm.py:123-125
+    cond_mask = lens_to_mask(lens)
+    if edit_mask is not None:
+        cond_mask = cond_mask & edit_mask
+    if isinstance(duration, int):
+        duration = torch.full((b,), duration, dtype=torch.long)
+    duration = torch.maximum(lens + 1, duration).clamp(max=max_duration)    # cfm.py:136-137
+    nmax = int(duration.amax())
+    cond = F.pad(cond, (0, 0, 0, nmax - cond_len), value=0.0)
+    cond_mask = F.pad(cond_mask, (0, nmax - cond_mask.shape[-1]), value=False)[..., None]
+    step_cond = torch.where(cond_mask, cond, torch.zeros_like(cond))
+    mask = lens_to_mask(duration) if b > 1 else None                        # cfm.py:151-154
+    if no_ref_audio:
+        cond = torch.zeros_like(cond)
+
+    def fn(t, x):
+        pred = fwd(x=x, cond=step_cond, text=text, time=t, mask=mask, drop_audio_cond=False, drop_text=False)
+        if cfg_strength < 1e-5:
+            return pred
+        null = fwd(x=x, cond=step_cond, text=text, time=t, mask=mask, drop_audio_cond=True, drop_text=True)
+        return pred + (pred - null) * cfg_strength
+
+    y0 = make_noise(duration, cfg.mel_dim, seed, y0)
+    t = sway_time_grid(steps, sway_sampling_coef)
+    traj = euler_odeint(fn, y0, t, keep_trajectory=keep_trajectory)
+    last = traj[-1] if keep_trajectory else traj
+    out = torch.where(cond_mask, cond, last)
+    return out, (traj if keep_trajectory else None)
