@@ -1,0 +1,114 @@
+/* libf5hip — C ABI of the MI355X-native F5-TTS inference hot path.
+ *
+ * Plain C, plain pointers and sizes, no torch types.  Pointers named *_dev are HIP device pointers
+ * (e.g. torch tensor .data_ptr() on a ROCm device), all other pointers are host memory.  `stream` is a
+ * hipStream_t passed as void* (NULL = default stream).  Every function returns 0 on success and a negative
+ * code on failure; f5hip_last_error() gives the message.  Nothing here falls back to the CPU.
+ *
+ * Each entry point names the reference interface it replaces (F/ = src/server/f5_tts/ of
+ * dwani-ai/tts-indic-server-f5); INTEGRATION.md shows the ctypes binding a maintainer would add.
+ */
+#ifndef F5HIP_H
+#define F5HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define F5HIP_ABI_VERSION 1
+
+int f5hip_abi_version(void);
+const char* f5hip_last_error(void);
+
+/* ---------------------------------------------------------------- DiT backbone + CFM sampler ---------- */
+
+/* model.arch of F/configs/F5TTS_*_train.yaml:24-30 (+ mel_dim, vocab size: F/infer/utils_infer.py:240-242). */
+typedef struct f5hip_dit_config {
+    int32_t dim, depth, heads, ff_mult, text_dim, conv_layers, mel_dim, text_num_embeds;
+    int32_t gemm_planes; /* 2 = split-bf16 "bf16x3" GEMMs (parity mode, default), 1 = plain bf16 (fast, ~8e-3 mel RMS) */
+} f5hip_dit_config;
+
+typedef struct f5hip_dit f5hip_dit;
+
+/* Replaces DiT.__init__ (F/model/backbones/dit.py:94-128). */
+f5hip_dit* f5hip_dit_create(const f5hip_dit_config* cfg);
+void f5hip_dit_destroy(f5hip_dit* m);
+
+/* Replaces model.load_state_dict (F/infer/utils_infer.py:195-209): one call per tensor, `name` is the
+ * reference checkpoint key with the "ema_model." prefix stripped ("transformer.time_embed.time_mlp.0.weight", ...),
+ * `data` is host fp32 in the tensor's own row-major layout. */
+int f5hip_dit_load_param(f5hip_dit* m, const char* name, const float* data, int64_t numel);
+/* Checks that every parameter arrived, packs the weights for the MFMA kernels (split bf16, padded, fused QKV /
+ * AdaLN matrices) and uploads them.  Must be called once before any forward/sample call. */
+int f5hip_dit_finalize(f5hip_dit* m);
+
+/* One evaluation of DiT.forward (F/model/backbones/dit.py:130-163) for n_seq independent sequences.
+ *   seq_len[i]   frames of sequence i (rows of x/cond/out belonging to it, packed back to back)
+ *   kv_len[i]    valid keys (== seq_len[i] for mask=None; < seq_len reproduces the reference's padded-batch
+ *                key-padding mask and zeroed attention rows, F/model/modules.py:429-447)
+ *   x_dev, cond_dev  fp32 [sum(seq_len)][mel_dim];  text: int32 [n_seq][nt_max], -1 padded;  time: scalar t
+ *   drop_audio_cond[i], drop_text[i]: the two CFG switches of the reference signature
+ *   n_blocks     -1 = whole network (out_dev = [sum(seq_len)][mel_dim]); k >= 0 = stop after k transformer
+ *                blocks and return the residual stream in h_out_dev [sum(seq_len)][dim] (parity taps)
+ */
+int f5hip_dit_forward(f5hip_dit* m, int32_t n_seq, const int32_t* seq_len, const int32_t* kv_len,
+                      const float* x_dev, const float* cond_dev, const int32_t* text, int32_t nt_max, float time,
+                      const uint8_t* drop_audio_cond, const uint8_t* drop_text, int32_t n_blocks,
+                      float* out_dev, float* h_out_dev, void* stream);
+
+/* Copies an internal fp32 activation of the last forward for parity taps: "text_embed" -> [sum(seq_len)][text_dim]. */
+int f5hip_dit_read_tap(f5hip_dit* m, const char* tap, float* dst_dev, int64_t numel, void* stream);
+
+/* The ODE loop of CFM.sample (F/model/cfm.py:160-204): Euler over t_grid with classifier-free guidance,
+ * each utterance sampled with the reference's batch-1 semantics (mask=None).
+ *   dur[u]          total frames of utterance u (already max(lens+1, duration) clamped, cfm.py:136-137)
+ *   cond_dev        fp32 [sum(dur)][mel_dim] mel conditioning, zero padded to dur (cfm.py:144)
+ *   cond_mask       uint8 [sum(dur)] 1 where the frame is conditioning (cfm.py:129-131,145-146)
+ *   text            int32 [n_utt][nt_max] token ids, -1 padded (cfm.py:116-121)
+ *   y0_dev          fp32 [sum(dur)][mel_dim] initial noise (cfm.py:181-186)
+ *   t_grid          float [steps+1] (cfm.py:196-198)
+ *   cfg_strength    < 1e-5 skips the unconditional branch (cfm.py:170-171)
+ *   out_dev         fp32 [sum(dur)][mel_dim] = where(cond_mask, cond, x_1) (cfm.py:204)
+ */
+int f5hip_cfm_sample(f5hip_dit* m, int32_t n_utt, const int32_t* dur, const float* cond_dev,
+                     const uint8_t* cond_mask, const int32_t* text, int32_t nt_max, const float* y0_dev,
+                     const float* t_grid, int32_t steps, float cfg_strength, float* out_dev, void* stream);
+
+/* Per-kernel timing of the last f5hip_cfm_sample call when profiling was enabled with
+ * f5hip_set_profiling(1): average milliseconds per launch of the named kernel class
+ * ("gemm", "attn", "ln", "other") measured with HIP events on the launch stream, and launch counts. */
+int f5hip_set_profiling(int32_t enabled);
+int f5hip_get_profile(const char* kernel_class, double* total_ms, int64_t* launches);
+
+/* ---------------------------------------------------------------- Vocos vocoder ----------------------- */
+
+typedef struct f5hip_vocos_config {
+    int32_t in_channels, dim, intermediate_dim, num_layers, n_fft, hop_length;
+    int32_t gemm_planes;
+} f5hip_vocos_config;
+typedef struct f5hip_vocos f5hip_vocos;
+
+/* Replaces Vocos.from_hparams + load_state_dict (F/infer/utils_infer.py:104-115); names are vocos 0.1.0 keys
+ * ("backbone.embed.weight", "backbone.convnext.0.dwconv.weight", ..., "head.out.weight"). */
+f5hip_vocos* f5hip_vocos_create(const f5hip_vocos_config* cfg);
+void f5hip_vocos_destroy(f5hip_vocos* v);
+int f5hip_vocos_load_param(f5hip_vocos* v, const char* name, const float* data, int64_t numel);
+int f5hip_vocos_finalize(f5hip_vocos* v);
+/* Replaces vocoder.decode(mel) (F/infer/utils_infer.py:472): mel_dev fp32 [batch][in_channels][frames] ->
+ * wave_dev fp32 [batch][hop_length * (frames - 1)]. */
+int f5hip_vocos_decode(f5hip_vocos* v, int32_t batch, int32_t frames, const float* mel_dev, float* wave_dev,
+                       void* stream);
+
+/* ---------------------------------------------------------------- mel front-end ------------------------ */
+
+/* Replaces MelSpec.forward with mel_spec_type="vocos" (F/model/modules.py:75-101,130-143): wave_dev fp32
+ * [batch][n_samples] -> mel_dev fp32 [batch][n_mels][1 + n_samples / hop] (log of clamp(mel, 1e-5)). */
+int f5hip_mel_spectrogram(int32_t batch, int32_t n_samples, const float* wave_dev, float* mel_dev, int32_t n_fft,
+                          int32_t hop_length, int32_t n_mels, int32_t sample_rate, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* F5HIP_H */

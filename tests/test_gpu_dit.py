@@ -1,0 +1,121 @@
+"""GPU parity (through the C ABI): HIP DiT / CFM path vs the fp32 CPU oracle and the golden fixtures produced
+from the reference's own modules.  Tolerances: BASELINE.json north_star = 1e-3 RMS on mel frames."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import dit_oracle as O  # noqa: E402
+from tts_indic_server_f5_amd import synth  # noqa: E402
+
+TINY = dict(dim=128, depth=2, heads=2, ff_mult=2, text_dim=64, conv_layers=2, text_num_embeds=40)
+
+
+def _load(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    return {k: torch.from_numpy(z[k]) for k in z.files}
+
+
+def _rms(a, b):
+    return (a.float().cpu() - b.float().cpu()).pow(2).mean().sqrt().item()
+
+
+def _report(tag, got, ref):
+    got, ref = got.float().cpu(), ref.float().cpu()
+    d = (got - ref)
+    print(f"[parity] {tag}: rms_err {d.pow(2).mean().sqrt():.3e} max_err {d.abs().max():.3e} ref_rms {ref.pow(2).mean().sqrt():.3e}")
+    return d.pow(2).mean().sqrt().item()
+
+
+@pytest.fixture(scope="module")
+def tiny_model():
+    from tts_indic_server_f5_amd.model import DiTArch, F5HipModel
+    return F5HipModel(DiTArch(**TINY), synth.dit_state_dict(**TINY))
+
+
+def test_tiny_taps_vs_reference_fixture(golden_dir, tiny_model):
+    """text_embed / input_embed / block0 / full forward of the reference's own modules (fixture), b=1."""
+    g = _load(golden_dir, "dit_tiny_forward")
+    x, cond, text, tm = g["x"][:1], g["cond"][:1], g["text"][:1], float(g["time"])
+    n = x.shape[1]
+    h0 = tiny_model.transformer_forward(x, cond, text, tm, False, False, n_blocks=0)
+    te = tiny_model.read_tap("text_embed", n, TINY["text_dim"])
+    assert _report("text_embed", te, g["text_embed"][0]) < 2e-4
+    assert _report("input_embed", h0, g["input_embed"]) < 3e-4
+    h1 = tiny_model.transformer_forward(x, cond, text, tm, False, False, n_blocks=1)
+    assert _report("block0", h1, g["block0"]) < 5e-4
+    for tag, da, dt in (("cond", False, False), ("null", True, True)):
+        out = tiny_model.transformer_forward(x, cond, text, tm, da, dt)
+        assert _report("forward b1 " + tag, out, g["out_b1_" + tag]) < 1e-3
+
+
+def test_tiny_forward_padded_batch_mask(golden_dir, tiny_model):
+    """b=3 with unequal lengths: the reference's padded-batch semantics (key-padding mask, zeroed rows)."""
+    g = _load(golden_dir, "dit_tiny_forward")
+    mask = O.lens_to_mask(g["lens"], g["x"].shape[1])
+    for tag, da, dt in (("cond", False, False), ("null", True, True)):
+        out = tiny_model.transformer_forward(g["x"], g["cond"], g["text"], float(g["time"]), da, dt, mask=mask)
+        assert _report("forward b3 mask " + tag, out, g["out_b3_mask_" + tag]) < 1e-3
+
+
+def test_tiny_cfm_sample_vs_reference_fixture(golden_dir, tiny_model):
+    g = _load(golden_dir, "cfm_sample_tiny")
+    for steps in (4, 16):
+        for sway in (None, -1.0):
+            for cfg in (0.0, 2.0):
+                key = f"s{steps}_sw{'n' if sway is None else 'm1'}_cfg{int(cfg)}"
+                out, _ = tiny_model.sample(g["cond1"], g["text1"], 48, steps=steps, cfg_strength=cfg,
+                                           sway_sampling_coef=sway, seed=7)
+                ref = g[key + "_b1_out"]
+                assert _report("sample " + key, out[:, 17:], ref[:, 17:]) < 1e-3
+                assert torch.equal(out[:, :17].cpu(), ref[:, :17])   # conditioning frames are copied exactly
+    out, _ = tiny_model.sample(g["cond1"][:, :10], g["text1"], 12, steps=4, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=7)
+    assert _report("sample longtext", out, g["longtext_out"]) < 1e-3
+
+
+def test_small_forward_vs_reference_fixture(golden_dir):
+    from tts_indic_server_f5_amd.model import F5TTS_SMALL, F5HipModel
+    g = _load(golden_dir, "dit_small_forward")
+    m = F5HipModel(F5TTS_SMALL, synth.dit_state_dict(dim=768, depth=18, heads=12))
+    o1 = m.transformer_forward(g["x"], g["cond"], g["text"], 0.5, False, False)
+    o2 = m.transformer_forward(g["x"], g["cond"], g["text"], 0.5, True, True)
+    assert _report("small forward cond", o1, g["out_cond"]) < 1e-3
+    assert _report("small forward null", o2, g["out_null"]) < 1e-3
+    m1 = F5HipModel(F5TTS_SMALL, synth.dit_state_dict(dim=768, depth=18, heads=12), gemm_planes=1)
+    o1f = m1.transformer_forward(g["x"], g["cond"], g["text"], 0.5, False, False)
+    e = _report("small forward cond [plain bf16 mode]", o1f, g["out_cond"])
+    assert e < 5e-2   # fast mode: documented to miss the 1e-3 bound
+
+
+@pytest.fixture(scope="module")
+def base_model():
+    from tts_indic_server_f5_amd.model import F5TTS_BASE, F5HipModel
+    return F5HipModel(F5TTS_BASE, synth.dit_state_dict())
+
+
+def test_base_forward_digest(golden_dir, base_model):
+    """Full-size F5-Base forward at the C2 geometry (N = 1404) against the digest of the reference's output."""
+    g = _load(golden_dir, "dit_base_forward_digest")
+    x = synth.noise(1404, 0)[None]
+    out = base_model.transformer_forward(x, g["cond"].float(), synth.text_ids(), 0.25, False, False)
+    got = out.flatten().cpu()[g["idx"]]
+    assert _report("base forward (4096 sampled)", got, g["sampled"]) < 1e-3
+    assert abs(out.mean().item() - float(g["mean"])) < 1e-3 and abs(out.std().item() - float(g["std"])) < 1e-3
+
+
+def test_base_sample_vs_oracle_short(base_model):
+    """F5-Base, C2 geometry, 4 Euler steps with CFG vs the CPU oracle (the oracle needs ~15 s for this)."""
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    sd = synth.dit_state_dict()
+    gsd = torch.Generator().manual_seed(14)
+    cond = torch.randn(1, 469, 100, generator=gsd)
+    text = synth.text_ids()
+    y0 = synth.noise(1404, 0)[None]
+    ref, _ = O.cfm_sample(sd, O.F5_BASE, cond, text, 1404, steps=4, cfg_strength=2.0, sway_sampling_coef=-1.0, y0=y0,
+                          keep_trajectory=False)
+    out, _ = base_model.sample(cond, text, 1404, steps=4, cfg_strength=2.0, sway_sampling_coef=-1.0, y0=y0)
+    assert _report("base sample 4 steps (generated frames)", out[:, 469:], ref[:, 469:]) < 1e-3
+    assert torch.equal(out[:, :469].cpu(), ref[:, :469])

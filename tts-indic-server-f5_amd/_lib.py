@@ -1,0 +1,80 @@
+"""ctypes binding of libf5hip (include/f5hip.h).  Fails loudly when the HIP library is missing: there is no
+CPU path in this package."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "csrc", "libf5hip.so")
+
+_lib = None
+
+
+class DitConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("dim", "depth", "heads", "ff_mult", "text_dim", "conv_layers", "mel_dim",
+                                          "text_num_embeds", "gemm_planes")]
+
+
+class VocosConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("in_channels", "dim", "intermediate_dim", "num_layers", "n_fft", "hop_length",
+                                          "gemm_planes")]
+
+
+# every symbol include/f5hip.h declares: (restype, argtypes)
+SYMBOLS = {
+    "f5hip_abi_version": (C.c_int, []),
+    "f5hip_last_error": (C.c_char_p, []),
+    "f5hip_dit_create": (C.c_void_p, [C.POINTER(DitConfig)]),
+    "f5hip_dit_destroy": (None, [C.c_void_p]),
+    "f5hip_dit_load_param": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]),
+    "f5hip_dit_finalize": (C.c_int, [C.c_void_p]),
+    "f5hip_dit_forward": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_int32, C.c_float, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                                    C.c_void_p]),
+    "f5hip_dit_read_tap": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "f5hip_cfm_sample": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                   C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),
+    "f5hip_set_profiling": (C.c_int, [C.c_int32]),
+    "f5hip_get_profile": (C.c_int, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "f5hip_vocos_create": (C.c_void_p, [C.POINTER(VocosConfig)]),
+    "f5hip_vocos_destroy": (None, [C.c_void_p]),
+    "f5hip_vocos_load_param": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]),
+    "f5hip_vocos_finalize": (C.c_int, [C.c_void_p]),
+    "f5hip_vocos_decode": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "f5hip_mel_spectrogram": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                        C.c_int32, C.c_void_p]),
+}
+
+
+class F5HipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Loads libf5hip.so (once).  Raises F5HipError if it has not been built: no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise F5HipError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                             "(this package has no CPU fallback)")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        if l.f5hip_abi_version() != 1:
+            raise F5HipError("libf5hip ABI version mismatch")
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise F5HipError(f"{what} failed ({rc}): {lib().f5hip_last_error().decode(errors='replace')}")
+
+
+def current_stream_ptr():
+    """hipStream_t of torch's current stream on the current device, as an int for the `stream` arguments."""
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,65 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels of libf5hip.
+// Wave = 64 lanes everywhere; bf16 MFMA fragments are 8 x bf16 = one 16-byte register quad.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define F5_DEVICE __device__ __forceinline__
+
+// fp32 -> (hi, lo) bf16 pair with hi = rn(x), lo = rn(x - hi): x ~= hi + lo to ~16 mantissa bits.
+F5_DEVICE void split_bf16(float x, __bf16& hi, __bf16& lo) {
+    hi = (__bf16)x;
+    lo = (__bf16)(x - (float)hi);
+}
+
+F5_DEVICE void split_bf16x4(const float* y, bf16x4& hi, bf16x4& lo) {
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        __bf16 h, l;
+        split_bf16(y[e], h, l);
+        hi[e] = h;
+        lo[e] = l;
+    }
+}
+
+F5_DEVICE float gelu_tanh_f(float x) {
+    // torch GELU(approximate="tanh"): 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
+    const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+    float u = k0 * (x + k1 * x * x * x);
+    return 0.5f * x * (1.0f + tanhf(u));
+}
+F5_DEVICE float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f)); }
+F5_DEVICE float silu_f(float x) { return x / (1.0f + expf(-x)); }
+F5_DEVICE float mish_f(float x) {
+    // x * tanh(softplus(x)), softplus with torch's threshold 20
+    float sp = x > 20.0f ? x : log1pf(expf(x));
+    return x * tanhf(sp);
+}
+
+F5_DEVICE float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+F5_DEVICE float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+enum { ACT_NONE = 0, ACT_GELU_TANH = 1, ACT_GELU_ERF = 2, ACT_MISH = 3, ACT_SILU = 4 };
+
+F5_DEVICE float apply_act(float v, int act) {
+    switch (act) {
+        case ACT_GELU_TANH: return gelu_tanh_f(v);
+        case ACT_GELU_ERF: return gelu_erf_f(v);
+        case ACT_MISH: return mish_f(v);
+        case ACT_SILU: return silu_f(v);
+        default: return v;
+    }
+}

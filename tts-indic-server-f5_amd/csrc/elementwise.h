@@ -1,0 +1,220 @@
+// HBM/L2-bound row kernels of the DiT / Vocos paths: LayerNorm (+AdaLN modulation, + optional depthwise
+// conv k=7 in front), GRN, embedding gather, CFG + Euler update, packing helpers.  One wave (64 lanes) per
+// row, float4 loads, wave-shuffle reductions, fp32 statistics, split-bf16 outputs that feed the MFMA GEMMs.
+#pragma once
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm over the last dim (biased variance, eps inside the sqrt, like torch), then
+//   y = n * (gain_off + scale[c]) + shift[c]
+// AdaLN-Zero: gain_off = 1, scale/shift from the modulation vector (F/model/modules.py:289,568,310);
+// affine LayerNorm: gain_off = 0, scale = weight, shift = bias (ConvNeXt blocks).
+// With dw_w != null the row is first replaced by a depthwise Conv1d(k=7, pad=3) over the frame axis
+// (zero padding at the sequence bounds): F/model/modules.py:262 / vocos ConvNeXtBlock.
+struct LnArgs {
+    const float* x; int ldx; int M; int D;
+    const float* scale; const float* shift; float gain_off; float eps;
+    const float* dw_w; const float* dw_b; const int* row_seq_start; const int* row_seq_end;
+    __bf16* out_hi; __bf16* out_lo; int ldo;
+    float* out_f32; int ldof;
+};
+
+template <int NV>
+__global__ __launch_bounds__(256) void ln_kernel(const LnArgs p) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= p.M) return;
+    float4 v[NV];
+    float sum = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+        const int c = (i * 64 + lane) * 4;
+        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < p.D) {
+            if (p.dw_w) {
+                const int s0 = p.row_seq_start[row], s1 = p.row_seq_end[row];
+                float4 a = *reinterpret_cast<const float4*>(p.dw_b + c);
+#pragma unroll
+                for (int k = 0; k < 7; k++) {
+                    const int r = row + k - 3;
+                    if (r >= s0 && r < s1) {
+                        const float4 xv = *reinterpret_cast<const float4*>(p.x + (size_t)r * p.ldx + c);
+                        a.x += p.dw_w[(c + 0) * 7 + k] * xv.x;
+                        a.y += p.dw_w[(c + 1) * 7 + k] * xv.y;
+                        a.z += p.dw_w[(c + 2) * 7 + k] * xv.z;
+                        a.w += p.dw_w[(c + 3) * 7 + k] * xv.w;
+                    }
+                }
+                v[i] = a;
+            } else {
+                v[i] = *reinterpret_cast<const float4*>(p.x + (size_t)row * p.ldx + c);
+            }
+            sum += v[i].x + v[i].y + v[i].z + v[i].w;
+        }
+    }
+    const float mean = wave_sum(sum) / (float)p.D;
+    float sq = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < p.D) {
+            const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+            sq += a * a + b * b + cc * cc + d * d;
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(sq) / (float)p.D + p.eps);
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < p.D) {
+            const float4 sc = *reinterpret_cast<const float4*>(p.scale + c);
+            const float4 sh = *reinterpret_cast<const float4*>(p.shift + c);
+            float y[4];
+            y[0] = (v[i].x - mean) * rstd * (p.gain_off + sc.x) + sh.x;
+            y[1] = (v[i].y - mean) * rstd * (p.gain_off + sc.y) + sh.y;
+            y[2] = (v[i].z - mean) * rstd * (p.gain_off + sc.z) + sh.z;
+            y[3] = (v[i].w - mean) * rstd * (p.gain_off + sc.w) + sh.w;
+            if (p.out_f32) *reinterpret_cast<float4*>(p.out_f32 + (size_t)row * p.ldof + c) = make_float4(y[0], y[1], y[2], y[3]);
+            if (p.out_hi) {
+                bf16x4 hi, lo;
+                split_bf16x4(y, hi, lo);
+                *reinterpret_cast<bf16x4*>(p.out_hi + (size_t)row * p.ldo + c) = hi;
+                if (p.out_lo) *reinterpret_cast<bf16x4*>(p.out_lo + (size_t)row * p.ldo + c) = lo;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// GRN (F/model/modules.py:231-234): Gx[c] = ||y[:, c]||_2 over the frames of one sequence.
+__global__ __launch_bounds__(256) void grn_stats_kernel(const float* y, int ldy, int C, const int* seq_row0,
+                                                        const int* seq_len, float* gx /*[n_seq][C]*/) {
+    const int seq = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const int r0 = seq_row0[seq], n = seq_len[seq];
+    float acc = 0.0f;
+    for (int r = 0; r < n; r++) {
+        const float t = y[(size_t)(r0 + r) * ldy + c];
+        acc += t * t;
+    }
+    gx[(size_t)seq * C + c] = sqrtf(acc);
+}
+
+// y' = gamma * (y * Nx) + beta + y,  Nx = Gx / (mean_c(Gx) + 1e-6)  -> split bf16
+__global__ __launch_bounds__(256) void grn_apply_kernel(const float* y, int ldy, int C, int M, const int* row_seq,
+                                                        const float* gx, const float* gamma, const float* beta,
+                                                        __bf16* out_hi, __bf16* out_lo, int ldo) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int seq = row_seq[row];
+    if (seq < 0) return;
+    const float* g = gx + (size_t)seq * C;
+    float s = 0.0f;
+    for (int c = lane; c < C; c += 64) s += g[c];
+    const float denom = wave_sum(s) / (float)C + 1e-6f;
+    for (int c = lane * 4; c < C; c += 256) {
+        const float4 yv = *reinterpret_cast<const float4*>(y + (size_t)row * ldy + c);
+        const float yy[4] = {yv.x, yv.y, yv.z, yv.w};
+        bf16x4 hi, lo;
+        float ov[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const float nx = g[c + e] / denom;
+            ov[e] = gamma[c + e] * (yy[e] * nx) + beta[c + e] + yy[e];
+        }
+        split_bf16x4(ov, hi, lo);
+        *reinterpret_cast<bf16x4*>(out_hi + (size_t)row * ldo + c) = hi;
+        if (out_lo) *reinterpret_cast<bf16x4*>(out_lo + (size_t)row * ldo + c) = lo;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Text embedding gather (F/model/backbones/dit.py:48-64): e[m] = Embedding[id[m]] + pos_table[min(pos, 4095)]
+__global__ __launch_bounds__(256) void text_gather_kernel(const float* emb, const float* pos_table, int C, int M,
+                                                          const int* row_token, const int* row_pos, int add_pos,
+                                                          float* out, int ldo) {
+    const int row = blockIdx.x;
+    if (row >= M) return;
+    const int tok = row_token[row];
+    if (tok < 0) return;   // padding row of the packed layout
+    const int pos = min(row_pos[row], 4095);
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float v = emb[(size_t)tok * C + c];
+        if (add_pos) v += pos_table[(size_t)pos * C + c];
+        out[(size_t)row * ldo + c] = v;
+    }
+}
+
+// fp32 [rows][C] -> split bf16 [rows][ldo] (columns >= C are left untouched: buffers are zero-initialised)
+__global__ __launch_bounds__(256) void split_rows_kernel(const float* x, int ldx, int C, int M, const int* row_src,
+                                                         __bf16* out_hi, __bf16* out_lo, int ldo, int col0) {
+    const int row = blockIdx.x;
+    if (row >= M) return;
+    const int src = row_src ? row_src[row] : row;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        __bf16 hi, lo;
+        const float v = src >= 0 ? x[(size_t)src * ldx + c] : 0.0f;
+        split_bf16(v, hi, lo);
+        out_hi[(size_t)row * ldo + col0 + c] = hi;
+        if (out_lo) out_lo[(size_t)row * ldo + col0 + c] = lo;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// CFG combine + Euler step (F/model/cfm.py:176 and torchdiffeq fixed-grid Euler):
+//   v = p + (p - p0) * cfg ;  x += dt * v
+// pred: [M_pad][ldp] rows of the conditional branch at row_c[u], unconditional at row_u[u] (or -1).
+// Also refreshes the split-bf16 copy of x that feeds the next step's input projection for both branches.
+__global__ __launch_bounds__(128) void cfg_euler_kernel(float* xstate /*[U][mel]*/, int mel, int U, const float* pred,
+                                                        int ldp, const int* urow_c, const int* urow_u, float cfg,
+                                                        float dt, __bf16* xs_hi, __bf16* xs_lo, int ldx) {
+    const int u = blockIdx.x;
+    if (u >= U) return;
+    const int c = threadIdx.x;
+    if (c >= mel) return;
+    const int rc = urow_c[u], ru = urow_u[u];
+    const float pc = pred[(size_t)rc * ldp + c];
+    float v = pc;
+    if (ru >= 0) v = pc + (pc - pred[(size_t)ru * ldp + c]) * cfg;
+    const float xn = xstate[(size_t)u * mel + c] + dt * v;
+    xstate[(size_t)u * mel + c] = xn;
+    __bf16 hi, lo;
+    split_bf16(xn, hi, lo);
+    xs_hi[(size_t)rc * ldx + c] = hi;
+    xs_lo[(size_t)rc * ldx + c] = lo;
+    if (ru >= 0) {
+        xs_hi[(size_t)ru * ldx + c] = hi;
+        xs_lo[(size_t)ru * ldx + c] = lo;
+    }
+}
+
+// out = cond_mask ? cond : x  (F/model/cfm.py:204); one block per utterance frame
+__global__ __launch_bounds__(128) void final_select_kernel(const float* xstate, const float* cond, const int* frame_is_cond,
+                                                           int mel, int U, float* out) {
+    const int u = blockIdx.x, c = threadIdx.x;
+    if (u >= U || c >= mel) return;
+    out[(size_t)u * mel + c] = frame_is_cond[u] ? cond[(size_t)u * mel + c] : xstate[(size_t)u * mel + c];
+}
+
+// fp32 [R][C] (row-major, ld = C) -> split bf16 [R_pad][C_pad] with zero fill; used by the weight packer
+__global__ __launch_bounds__(256) void pack_weight_kernel(const float* w, int R, int C, int ldw, __bf16* hi, __bf16* lo,
+                                                          int C_pad) {
+    const int r = blockIdx.x;
+    for (int c = threadIdx.x; c < C_pad; c += 256) {
+        float v = (r < R && c < C) ? w[(size_t)r * ldw + c] : 0.0f;
+        __bf16 h, l;
+        split_bf16(v, h, l);
+        hi[(size_t)r * C_pad + c] = h;
+        lo[(size_t)r * C_pad + c] = l;
+    }
+}
+
+// dst[f][0..C) = src[frame_row[f]][0..C): packed-row layout -> caller's frame order
+__global__ __launch_bounds__(128) void gather_rows_kernel(const float* src, int lds, int C, int n_frames, const int* frame_row,
+                                                          float* dst, int ldd) {
+    const int f = blockIdx.x;
+    if (f >= n_frames) return;
+    const int r = frame_row[f];
+    for (int c = threadIdx.x; c < C; c += 128) dst[(size_t)f * ldd + c] = src[(size_t)r * lds + c];
+}

@@ -1,0 +1,643 @@
+// libf5hip: C ABI (include/f5hip.h) + host orchestration of the DiT / CFM path on one MI355X.
+// One process per GPU; every call enqueues its kernels on the caller's HIP stream.
+#include "../../include/f5hip.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "attn.h"
+#include "common.h"
+#include "elementwise.h"
+#include "gemm.h"
+#include "host_util.h"
+
+// =================================================================================================
+// DiT model
+// =================================================================================================
+
+struct TextBlock {
+    float *dw_w = nullptr, *dw_b = nullptr, *ln_w = nullptr, *ln_b = nullptr, *gamma = nullptr, *beta = nullptr;
+    PackedW pw1, pw2;
+};
+
+struct f5hip_dit {
+    f5hip_dit_config cfg;
+    int nsplit = 2;
+    std::map<std::string, std::vector<float>> host;
+    bool finalized = false;
+    // packed weights
+    PackedW time1, time2, adaln, wx, wct, conv1, conv2, proj_out;
+    std::vector<PackedW> wqkv, wout, wff1, wff2;
+    std::vector<TextBlock> tblk;
+    float *text_emb = nullptr, *text_pos = nullptr, *rope_cos = nullptr, *rope_sin = nullptr;
+    int gw = 0;       // conv_pos_embed channels per group
+    int n_adaln = 0;  // depth * 6 D + 2 D
+    // workspace
+    int cap_rows = 0, cap_frames = 0, cap_seq = 0;
+    DevBuf ws;   // one arena, carved below
+    float *h = nullptr, *h0 = nullptr, *ce = nullptr, *pred = nullptr, *te = nullptr, *ty = nullptr, *gx = nullptr,
+          *mod = nullptr, *xstate = nullptr;
+    Plane2 hn, c1, ao, ff, xs, tn, tg, act, sinp, t1, st;
+    __bf16 *qk = nullptr, *vt = nullptr;
+    int *meta = nullptr;   // device int arena
+    int meta_cap = 0;
+    // per-call metadata (device pointers into `meta`)
+    int *d_row_pos, *d_row_start, *d_row_end, *d_row_seq, *d_row_token, *d_row_frame, *d_row_condframe, *d_row_keep,
+        *d_seq_row0, *d_seq_len, *d_seq_kvlen, *d_urow_c, *d_urow_u, *d_frame_is_cond;
+    int M = 0, M_pad = 0, n_seq = 0, n_frames = 0, max_len = 0;
+    bool any_masked = false;
+    std::vector<int> h_seq_len;
+};
+
+static int ceil_to(int v, int m) { return (v + m - 1) / m * m; }
+
+f5hip_dit* f5hip_dit_create(const f5hip_dit_config* cfg) {
+    if (!cfg) { set_error("null config"); return nullptr; }
+    if (cfg->dim % 128 || cfg->dim != cfg->heads * 64 || cfg->dim % 16 || cfg->text_dim % 32 || cfg->mel_dim > 128 ||
+        cfg->dim / 16 > 64 || (cfg->gemm_planes != 1 && cfg->gemm_planes != 2)) {
+        set_error("unsupported DiT geometry (need dim %% 128 == 0, dim == 64*heads, dim/16 <= 64, text_dim %% 32 == 0, mel_dim <= 128)");
+        return nullptr;
+    }
+    int dev_count = 0;
+    if (hipGetDeviceCount(&dev_count) != hipSuccess || dev_count == 0) {
+        set_error("no HIP device: libf5hip has no CPU fallback");
+        return nullptr;
+    }
+    f5hip_dit* m = new f5hip_dit();
+    m->cfg = *cfg;
+    m->nsplit = cfg->gemm_planes;
+    m->gw = cfg->dim / 16;
+    m->n_adaln = cfg->depth * 6 * cfg->dim + 2 * cfg->dim;
+    return m;
+}
+
+static void free_packed(PackedW& w) { dev_free(w.hi); dev_free(w.lo); dev_free(w.bias); w = PackedW(); }
+
+void f5hip_dit_destroy(f5hip_dit* m) {
+    if (!m) return;
+    for (PackedW* w : {&m->time1, &m->time2, &m->adaln, &m->wx, &m->wct, &m->conv1, &m->conv2, &m->proj_out}) free_packed(*w);
+    for (auto* v : {&m->wqkv, &m->wout, &m->wff1, &m->wff2}) for (auto& w : *v) free_packed(w);
+    for (auto& b : m->tblk) {
+        for (float* p : {b.dw_w, b.dw_b, b.ln_w, b.ln_b, b.gamma, b.beta}) dev_free(p);
+        free_packed(b.pw1); free_packed(b.pw2);
+    }
+    for (float* p : {m->text_emb, m->text_pos, m->rope_cos, m->rope_sin}) dev_free(p);
+    dev_free(m->ws.ptr);
+    dev_free(m->meta);
+    delete m;
+}
+
+int f5hip_dit_load_param(f5hip_dit* m, const char* name, const float* data, int64_t numel) {
+    if (!m || !name || !data || numel <= 0) return fail(-1, "load_param: bad argument");
+    if (m->finalized) return fail(-2, "load_param after finalize");
+    m->host[name].assign(data, data + numel);
+    return 0;
+}
+
+static const std::vector<float>* get_param(f5hip_dit* m, const std::string& name, int64_t numel) {
+    auto it = m->host.find(name);
+    if (it == m->host.end()) { set_error("missing parameter %s", name.c_str()); return nullptr; }
+    if ((int64_t)it->second.size() != numel) {
+        set_error("parameter %s has %lld elements, expected %lld", name.c_str(), (long long)it->second.size(), (long long)numel);
+        return nullptr;
+    }
+    return &it->second;
+}
+
+#define GETP(var, name, numel) const std::vector<float>* var = get_param(m, name, numel); if (!var) return -3;
+
+int f5hip_dit_finalize(f5hip_dit* m) {
+    if (!m) return fail(-1, "null model");
+    if (m->finalized) return 0;
+    const f5hip_dit_config& c = m->cfg;
+    const int D = c.dim, Td = c.text_dim, mel = c.mel_dim, F = c.ff_mult * D;
+    const std::string T = "transformer.";
+    // --- time MLP + all AdaLN linears (one [depth*6D + 2D, D] matrix: modulation depends on t only) ---
+    {
+        GETP(w0, T + "time_embed.time_mlp.0.weight", (int64_t)D * 256);
+        GETP(b0, T + "time_embed.time_mlp.0.bias", D);
+        GETP(w2, T + "time_embed.time_mlp.2.weight", (int64_t)D * D);
+        GETP(b2, T + "time_embed.time_mlp.2.bias", D);
+        if (pack_linear(m->time1, w0->data(), D, 256, 256, b0->data())) return -4;
+        if (pack_linear(m->time2, w2->data(), D, D, D, b2->data())) return -4;
+        std::vector<float> wa((size_t)m->n_adaln * D), ba(m->n_adaln);
+        for (int l = 0; l < c.depth; l++) {
+            std::string p = T + "transformer_blocks." + std::to_string(l) + ".attn_norm.linear.";
+            GETP(w, p + "weight", (int64_t)6 * D * D);
+            GETP(b, p + "bias", 6 * D);
+            memcpy(&wa[(size_t)l * 6 * D * D], w->data(), sizeof(float) * 6 * D * D);
+            memcpy(&ba[(size_t)l * 6 * D], b->data(), sizeof(float) * 6 * D);
+        }
+        GETP(wf, T + "norm_out.linear.weight", (int64_t)2 * D * D);
+        GETP(bfin, T + "norm_out.linear.bias", 2 * D);
+        memcpy(&wa[(size_t)c.depth * 6 * D * D], wf->data(), sizeof(float) * 2 * D * D);
+        memcpy(&ba[(size_t)c.depth * 6 * D], bfin->data(), sizeof(float) * 2 * D);
+        if (pack_linear(m->adaln, wa.data(), m->n_adaln, D, D, ba.data())) return -4;
+    }
+    // --- text embedding ---
+    {
+        GETP(e, T + "text_embed.text_embed.weight", (int64_t)(c.text_num_embeds + 1) * Td);
+        if (upload_f32(&m->text_emb, e->data(), e->size())) return -4;
+        // precompute_freqs_cis (F/model/modules.py:196-207): [cos(pos w_j) || sin(pos w_j)], fp32 angle
+        std::vector<float> tab((size_t)4096 * Td);
+        for (int pos = 0; pos < 4096; pos++)
+            for (int j = 0; j < Td / 2; j++) {
+                float w = 1.0f / powf(10000.0f, (float)(2 * j) / (float)Td);
+                float ang = (float)pos * w;
+                tab[(size_t)pos * Td + j] = (float)cos((double)ang);
+                tab[(size_t)pos * Td + Td / 2 + j] = (float)sin((double)ang);
+            }
+        if (upload_f32(&m->text_pos, tab.data(), tab.size())) return -4;
+        m->tblk.resize(c.conv_layers);
+        for (int i = 0; i < c.conv_layers; i++) {
+            std::string p = T + "text_embed.text_blocks." + std::to_string(i) + ".";
+            TextBlock& b = m->tblk[i];
+            GETP(dw, p + "dwconv.weight", (int64_t)Td * 7); GETP(db, p + "dwconv.bias", Td);
+            GETP(lw, p + "norm.weight", Td); GETP(lb, p + "norm.bias", Td);
+            GETP(w1, p + "pwconv1.weight", (int64_t)2 * Td * Td); GETP(b1, p + "pwconv1.bias", 2 * Td);
+            GETP(gg, p + "grn.gamma", 2 * Td); GETP(gb, p + "grn.beta", 2 * Td);
+            GETP(w2, p + "pwconv2.weight", (int64_t)2 * Td * Td); GETP(b2, p + "pwconv2.bias", Td);
+            if (upload_f32(&b.dw_w, dw->data(), dw->size()) || upload_f32(&b.dw_b, db->data(), db->size()) ||
+                upload_f32(&b.ln_w, lw->data(), lw->size()) || upload_f32(&b.ln_b, lb->data(), lb->size()) ||
+                upload_f32(&b.gamma, gg->data(), gg->size()) || upload_f32(&b.beta, gb->data(), gb->size())) return -4;
+            if (pack_linear(b.pw1, w1->data(), 2 * Td, Td, Td, b1->data())) return -4;
+            if (pack_linear(b.pw2, w2->data(), Td, 2 * Td, 2 * Td, b2->data())) return -4;
+        }
+    }
+    // --- input projection split by source: x part (changes every step) | cond + text part (step invariant) ---
+    {
+        const int Kin = 2 * mel + Td;
+        GETP(w, T + "input_embed.proj.weight", (int64_t)D * Kin);
+        GETP(b, T + "input_embed.proj.bias", D);
+        std::vector<float> wx((size_t)D * 128, 0.0f), wct((size_t)D * (128 + Td), 0.0f);
+        for (int n = 0; n < D; n++) {
+            for (int k = 0; k < mel; k++) {
+                wx[(size_t)n * 128 + k] = (*w)[(size_t)n * Kin + k];
+                wct[(size_t)n * (128 + Td) + k] = (*w)[(size_t)n * Kin + mel + k];
+            }
+            for (int k = 0; k < Td; k++) wct[(size_t)n * (128 + Td) + 128 + k] = (*w)[(size_t)n * Kin + 2 * mel + k];
+        }
+        if (pack_linear(m->wx, wx.data(), D, 128, 128, nullptr)) return -4;
+        if (pack_linear(m->wct, wct.data(), D, 128 + Td, 128 + Td, b->data())) return -4;
+    }
+    // --- conv_pos_embed: grouped Conv1d(D, D, 31, groups 16) as 16 implicit GEMMs, each padded to 64 x (31 x 64) ---
+    for (int which = 0; which < 2; which++) {
+        const int gw = m->gw;
+        std::string p = T + "input_embed.conv_pos_embed.conv1d." + std::to_string(which * 2) + ".";
+        GETP(w, p + "weight", (int64_t)D * gw * 31);
+        GETP(b, p + "bias", D);
+        const int K = 31 * 64;
+        std::vector<float> wp((size_t)16 * 64 * K, 0.0f), bp(16 * 64, 0.0f);
+        for (int g = 0; g < 16; g++)
+            for (int co = 0; co < gw; co++) {
+                bp[g * 64 + co] = (*b)[g * gw + co];
+                for (int ci = 0; ci < gw; ci++)
+                    for (int tap = 0; tap < 31; tap++)
+                        wp[((size_t)(g * 64 + co)) * K + tap * 64 + ci] = (*w)[((size_t)(g * gw + co) * gw + ci) * 31 + tap];
+            }
+        if (pack_linear(which ? m->conv2 : m->conv1, wp.data(), 16 * 64, K, K, bp.data())) return -4;
+    }
+    // --- transformer blocks ---
+    m->wqkv.resize(c.depth); m->wout.resize(c.depth); m->wff1.resize(c.depth); m->wff2.resize(c.depth);
+    for (int l = 0; l < c.depth; l++) {
+        std::string p = T + "transformer_blocks." + std::to_string(l) + ".";
+        std::vector<float> wq((size_t)3 * D * D), bq(3 * D);
+        const char* nm[3] = {"to_q", "to_k", "to_v"};
+        for (int i = 0; i < 3; i++) {
+            GETP(w, p + "attn." + nm[i] + ".weight", (int64_t)D * D);
+            GETP(b, p + "attn." + nm[i] + ".bias", D);
+            memcpy(&wq[(size_t)i * D * D], w->data(), sizeof(float) * D * D);
+            memcpy(&bq[(size_t)i * D], b->data(), sizeof(float) * D);
+        }
+        if (pack_linear(m->wqkv[l], wq.data(), 3 * D, D, D, bq.data())) return -4;
+        GETP(wo, p + "attn.to_out.0.weight", (int64_t)D * D); GETP(bo, p + "attn.to_out.0.bias", D);
+        if (pack_linear(m->wout[l], wo->data(), D, D, D, bo->data())) return -4;
+        GETP(w1, p + "ff.ff.0.0.weight", (int64_t)F * D); GETP(b1, p + "ff.ff.0.0.bias", F);
+        if (pack_linear(m->wff1[l], w1->data(), F, D, D, b1->data())) return -4;
+        GETP(w2, p + "ff.ff.2.weight", (int64_t)D * F); GETP(b2, p + "ff.ff.2.bias", D);
+        if (pack_linear(m->wff2[l], w2->data(), D, F, F, b2->data())) return -4;
+    }
+    {
+        GETP(w, T + "proj_out.weight", (int64_t)mel * D); GETP(b, T + "proj_out.bias", mel);
+        if (pack_linear(m->proj_out, w->data(), mel, D, D, b->data())) return -4;
+    }
+    // --- rotary tables (x-transformers 2.2.8 RotaryEmbedding): angle = pos * 10000^(-2i/64) in fp32 ---
+    {
+        std::vector<float> rc((size_t)4096 * 32), rs((size_t)4096 * 32);
+        for (int pos = 0; pos < 4096; pos++)
+            for (int i = 0; i < 32; i++) {
+                float inv = 1.0f / powf(10000.0f, (float)(2 * i) / 64.0f);
+                float ang = (float)pos * inv;
+                rc[(size_t)pos * 32 + i] = (float)cos((double)ang);
+                rs[(size_t)pos * 32 + i] = (float)sin((double)ang);
+            }
+        if (upload_f32(&m->rope_cos, rc.data(), rc.size()) || upload_f32(&m->rope_sin, rs.data(), rs.size())) return -4;
+    }
+    m->host.clear();
+    m->finalized = true;
+    return 0;
+}
+
+// -------------------------------------------------------------------------------------------------
+// workspace
+// -------------------------------------------------------------------------------------------------
+static int ensure_workspace(f5hip_dit* m, int rows_pad, int frames, int n_seq) {
+    if (rows_pad <= m->cap_rows && frames <= m->cap_frames && n_seq <= m->cap_seq) return 0;
+    const f5hip_dit_config& c = m->cfg;
+    const int D = c.dim, Td = c.text_dim, F = c.ff_mult * D;
+    const size_t R = (size_t)std::max(rows_pad, m->cap_rows), U = (size_t)std::max(frames, m->cap_frames),
+                 S = (size_t)std::max(n_seq, m->cap_seq);
+    dev_free(m->ws.ptr);
+    Arena a;
+    // pass 1 sizes, pass 2 pointers
+    for (int pass = 0; pass < 2; pass++) {
+        a.reset(pass ? (char*)m->ws.ptr : nullptr);
+        m->h = a.f32(R * D); m->h0 = a.f32(R * D); m->ce = a.f32(R * D); m->pred = a.f32(R * 128);
+        m->te = a.f32(R * Td); m->ty = a.f32(R * 2 * Td); m->gx = a.f32(S * 2 * Td);
+        m->mod = a.f32((size_t)128 * m->n_adaln); m->xstate = a.f32(U * c.mel_dim);
+        m->hn = a.plane2(R * D + 256); m->c1 = a.plane2(R * D + 256); m->ao = a.plane2(R * D); m->ff = a.plane2(R * F);
+        m->xs = a.plane2(R * 128); m->tn = a.plane2(R * Td); m->tg = a.plane2(R * 2 * Td); m->act = a.plane2(R * (128 + Td));
+        m->sinp = a.plane2(128 * 256); m->t1 = a.plane2((size_t)128 * D); m->st = a.plane2((size_t)128 * D);
+        m->qk = a.bf16(R * 2 * D); m->vt = a.bf16((size_t)D * R);
+        if (!pass) {
+            if (hipMalloc(&m->ws.ptr, a.used()) != hipSuccess) { m->ws.ptr = nullptr; m->cap_rows = 0; return fail(-5, "hipMalloc workspace %zu bytes", a.used()); }
+            if (hipMemset(m->ws.ptr, 0, a.used()) != hipSuccess) return fail(-5, "hipMemset workspace");
+        }
+    }
+    m->cap_rows = (int)R; m->cap_frames = (int)U; m->cap_seq = (int)S;
+    const int need = (int)(R * 8 + S * 3 + U * 3 + 64);
+    if (need > m->meta_cap) {
+        dev_free(m->meta);
+        if (hipMalloc((void**)&m->meta, sizeof(int) * need) != hipSuccess) { m->meta = nullptr; m->meta_cap = 0; return fail(-5, "hipMalloc meta"); }
+        m->meta_cap = need;
+    }
+    return 0;
+}
+
+struct SeqDesc { int len, kvlen, frame0 /* first frame in caller's packed arrays */, text_row, drop_audio, drop_text; };
+
+// Lays the sequences out (each padded to a multiple of 128 rows), builds the per-row metadata and uploads it.
+static int setup_sequences(f5hip_dit* m, const std::vector<SeqDesc>& seqs, int n_frames, const int32_t* text, int nt_max,
+                           const uint8_t* frame_is_cond, const std::vector<int>& urow_c, const std::vector<int>& urow_u,
+                           hipStream_t st) {
+    int rows = 0;
+    for (auto& s : seqs) rows += ceil_to(s.len, 128);
+    if (ensure_workspace(m, rows, n_frames, (int)seqs.size())) return -5;
+    const int R = rows, S = (int)seqs.size(), U = n_frames;
+    std::vector<int> hbuf((size_t)R * 8 + S * 3 + U * 3, 0);
+    int* row_pos = &hbuf[0]; int* row_start = row_pos + R; int* row_end = row_start + R; int* row_seq = row_end + R;
+    int* row_token = row_seq + R; int* row_frame = row_token + R; int* row_condframe = row_frame + R; int* row_keep = row_condframe + R;
+    int* seq_row0 = row_keep + R; int* seq_len = seq_row0 + S; int* seq_kvlen = seq_len + S;
+    int* d_urow_c = seq_kvlen + S; int* d_urow_u = d_urow_c + U; int* fic = d_urow_u + U;
+    int r0 = 0;
+    m->any_masked = false;
+    for (int r = 0; r < R; r++) { row_seq[r] = -1; row_token[r] = -1; row_frame[r] = -1; row_condframe[r] = -1; }
+    for (int s = 0; s < S; s++) {
+        const SeqDesc& q = seqs[s];
+        seq_row0[s] = r0; seq_len[s] = q.len; seq_kvlen[s] = q.kvlen;
+        if (q.kvlen < q.len) m->any_masked = true;
+        for (int i = 0; i < q.len; i++) {
+            const int r = r0 + i;
+            row_pos[r] = i; row_start[r] = r0; row_end[r] = r0 + q.len; row_seq[r] = s;
+            int tok = 0;
+            if (!q.drop_text && i < nt_max) tok = text[(size_t)q.text_row * nt_max + i] + 1;   // -1 pad -> filler 0
+            row_token[r] = tok;
+            row_frame[r] = q.frame0 + i;
+            const bool is_c = frame_is_cond ? frame_is_cond[q.frame0 + i] != 0 : true;
+            row_condframe[r] = (!q.drop_audio && is_c) ? q.frame0 + i : -1;
+            row_keep[r] = i < q.kvlen ? 1 : 0;
+        }
+        r0 += ceil_to(q.len, 128);
+    }
+    for (int u = 0; u < U; u++) {
+        d_urow_c[u] = u < (int)urow_c.size() ? urow_c[u] : -1;
+        d_urow_u[u] = u < (int)urow_u.size() ? urow_u[u] : -1;
+        fic[u] = frame_is_cond ? frame_is_cond[u] : 0;
+    }
+    if (hipMemcpyAsync(m->meta, hbuf.data(), sizeof(int) * hbuf.size(), hipMemcpyHostToDevice, st) != hipSuccess)
+        return fail(-6, "metadata upload");
+    if (hipStreamSynchronize(st) != hipSuccess) return fail(-6, "metadata upload sync");   // hbuf is a stack-scoped host buffer
+    int* d = m->meta;
+    m->d_row_pos = d; m->d_row_start = d + R; m->d_row_end = d + 2 * R; m->d_row_seq = d + 3 * R; m->d_row_token = d + 4 * R;
+    m->d_row_frame = d + 5 * R; m->d_row_condframe = d + 6 * R; m->d_row_keep = d + 7 * R;
+    d += 8 * R;
+    m->d_seq_row0 = d; m->d_seq_len = d + S; m->d_seq_kvlen = d + 2 * S; d += 3 * S;
+    m->d_urow_c = d; m->d_urow_u = d + U; m->d_frame_is_cond = d + 2 * U;
+    m->M = R; m->M_pad = R; m->n_seq = S; m->n_frames = U;
+    m->max_len = 0;
+    for (auto& q : seqs) m->max_len = std::max(m->max_len, q.len);
+    return 0;
+}
+
+// -------------------------------------------------------------------------------------------------
+// launch helpers
+// -------------------------------------------------------------------------------------------------
+static GemmArgs gemm_base(const Plane2& A, int lda, const PackedW& W, int M) {
+    GemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.A[0] = A.hi; a.A[1] = A.lo; a.lda = lda;
+    a.W[0] = W.hi; a.W[1] = W.lo;
+    a.M = M; a.N = W.n; a.K = W.k_pad;
+    a.bias = W.bias;
+    return a;
+}
+
+static int run_gemm(f5hip_dit* m, GemmArgs& a, const PackedW& W, int epi, bool conv, int bn, hipStream_t st, int m_pad = -1) {
+    hipError_t e;
+    const int mp = m_pad > 0 ? m_pad : m->M_pad, np = W.n_pad;
+    prof_begin(PROF_GEMM, st);
+    if (m->nsplit == 2) {
+        if (epi == EPI_QKV) e = launch_gemm_t<2, 128, false, EPI_QKV>(a, mp, np, st);
+        else if (conv && bn == 64) e = launch_gemm_t<2, 64, true, EPI_GENERIC>(a, mp, np, st);
+        else if (conv) e = launch_gemm_t<2, 128, true, EPI_GENERIC>(a, mp, np, st);
+        else if (bn == 64) e = launch_gemm_t<2, 64, false, EPI_GENERIC>(a, mp, np, st);
+        else e = launch_gemm_t<2, 128, false, EPI_GENERIC>(a, mp, np, st);
+    } else {
+        if (epi == EPI_QKV) e = launch_gemm_t<1, 128, false, EPI_QKV>(a, mp, np, st);
+        else if (conv && bn == 64) e = launch_gemm_t<1, 64, true, EPI_GENERIC>(a, mp, np, st);
+        else if (conv) e = launch_gemm_t<1, 128, true, EPI_GENERIC>(a, mp, np, st);
+        else if (bn == 64) e = launch_gemm_t<1, 64, false, EPI_GENERIC>(a, mp, np, st);
+        else e = launch_gemm_t<1, 128, false, EPI_GENERIC>(a, mp, np, st);
+    }
+    prof_end(PROF_GEMM, st);
+    if (e != hipSuccess) return fail(-7, "gemm launch: %s", hipGetErrorString(e));
+    return 0;
+}
+
+static int run_ln(const LnArgs& a, hipStream_t st) {
+    const int nv = (a.D + 255) / 256;
+    dim3 grid((a.M + 3) / 4), blk(256);
+    prof_begin(PROF_LN, st);
+    switch (nv) {
+        case 1: hipLaunchKernelGGL(ln_kernel<1>, grid, blk, 0, st, a); break;
+        case 2: hipLaunchKernelGGL(ln_kernel<2>, grid, blk, 0, st, a); break;
+        case 3: hipLaunchKernelGGL(ln_kernel<3>, grid, blk, 0, st, a); break;
+        case 4: hipLaunchKernelGGL(ln_kernel<4>, grid, blk, 0, st, a); break;
+        case 5: case 6: hipLaunchKernelGGL(ln_kernel<6>, grid, blk, 0, st, a); break;
+        default: return fail(-7, "ln: D=%d unsupported", a.D);
+    }
+    prof_end(PROF_LN, st);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(-7, "ln launch: %s", hipGetErrorString(e));
+    return 0;
+}
+
+#define CK(x) do { int _r = (x); if (_r) return _r; } while (0)
+#define CKL(name) do { hipError_t _e = hipGetLastError(); if (_e != hipSuccess) return fail(-7, "%s launch: %s", name, hipGetErrorString(_e)); } while (0)
+
+// -------------------------------------------------------------------------------------------------
+// step-invariant precompute: text embedding for every sequence, cond/text part of the input projection
+// -------------------------------------------------------------------------------------------------
+static int precompute_text_and_ce(f5hip_dit* m, const float* cond_dev, hipStream_t st) {
+    const f5hip_dit_config& c = m->cfg;
+    const int D = c.dim, Td = c.text_dim, M = m->M, Kct = 128 + Td;
+    prof_begin(PROF_OTHER, st);
+    hipLaunchKernelGGL(text_gather_kernel, dim3(M), dim3(256), 0, st, m->text_emb, m->text_pos, Td, M, m->d_row_token,
+                       m->d_row_pos, c.conv_layers > 0 ? 1 : 0, m->te, Td);
+    CKL("text_gather");
+    // audio-cond columns of the step-invariant operand (zero rows for dropped cond / non-cond frames / padding)
+    hipLaunchKernelGGL(split_rows_kernel, dim3(M), dim3(256), 0, st, cond_dev, c.mel_dim, c.mel_dim, M, m->d_row_condframe,
+                       m->act.hi, m->act.lo, Kct, 0);
+    CKL("split cond");
+    prof_end(PROF_OTHER, st);
+    for (int i = 0; i < c.conv_layers; i++) {
+        TextBlock& b = m->tblk[i];
+        LnArgs ln; memset(&ln, 0, sizeof(ln));
+        ln.x = m->te; ln.ldx = Td; ln.M = M; ln.D = Td; ln.scale = b.ln_w; ln.shift = b.ln_b; ln.gain_off = 0.0f; ln.eps = 1e-6f;
+        ln.dw_w = b.dw_w; ln.dw_b = b.dw_b; ln.row_seq_start = m->d_row_start; ln.row_seq_end = m->d_row_end;
+        ln.out_hi = m->tn.hi; ln.out_lo = m->tn.lo; ln.ldo = Td;
+        CK(run_ln(ln, st));
+        GemmArgs g1 = gemm_base(m->tn, Td, b.pw1, M);
+        g1.act = ACT_GELU_ERF; g1.out_f32 = m->ty; g1.ldo = 2 * Td;
+        CK(run_gemm(m, g1, b.pw1, EPI_GENERIC, false, 128, st));
+        prof_begin(PROF_OTHER, st);
+        hipLaunchKernelGGL(grn_stats_kernel, dim3((2 * Td + 255) / 256, m->n_seq), dim3(256), 0, st, m->ty, 2 * Td, 2 * Td,
+                           m->d_seq_row0, m->d_seq_len, m->gx);
+        CKL("grn_stats");
+        hipLaunchKernelGGL(grn_apply_kernel, dim3((M + 3) / 4), dim3(256), 0, st, m->ty, 2 * Td, 2 * Td, M, m->d_row_seq, m->gx,
+                           b.gamma, b.beta, m->tg.hi, m->tg.lo, 2 * Td);
+        CKL("grn_apply");
+        prof_end(PROF_OTHER, st);
+        GemmArgs g2 = gemm_base(m->tg, 2 * Td, b.pw2, M);
+        g2.res = m->te; g2.ldres = Td; g2.out_f32 = m->te; g2.ldo = Td;
+        if (i == c.conv_layers - 1) { g2.out_hi = m->act.hi + 128; g2.out_lo = m->act.lo + 128; g2.ldob = Kct; }
+        CK(run_gemm(m, g2, b.pw2, EPI_GENERIC, false, 128, st));
+    }
+    if (c.conv_layers == 0) {
+        prof_begin(PROF_OTHER, st);
+        hipLaunchKernelGGL(split_rows_kernel, dim3(M), dim3(256), 0, st, m->te, Td, Td, M, (const int*)nullptr, m->act.hi,
+                           m->act.lo, Kct, 128);
+        CKL("split text");
+        prof_end(PROF_OTHER, st);
+    }
+    GemmArgs g = gemm_base(m->act, Kct, m->wct, M);
+    g.out_f32 = m->ce; g.ldo = D;
+    CK(run_gemm(m, g, m->wct, EPI_GENERIC, false, 128, st));
+    return 0;
+}
+
+// time embedding + every AdaLN modulation vector for all steps at once (they depend on t only)
+static int precompute_time(f5hip_dit* m, const float* t_host, int n_t, hipStream_t st) {
+    const f5hip_dit_config& c = m->cfg;
+    const int D = c.dim;
+    if (n_t > 128) return fail(-8, "at most 128 time points per call (got %d)", n_t);
+    // SinusPositionEmbedding (F/model/modules.py:154-161) on the host: the table is n_t x 256
+    std::vector<uint16_t> hi((size_t)128 * 256, 0), lo((size_t)128 * 256, 0);
+    const float emb = logf(10000.0f) / (float)(128 - 1);
+    for (int i = 0; i < n_t; i++)
+        for (int k = 0; k < 128; k++) {
+            const float f = expf((float)k * -emb);
+            const float e = 1000.0f * t_host[i] * f;
+            const float sv = (float)sin((double)e), cv = (float)cos((double)e);
+            host_split_bf16(sv, hi[(size_t)i * 256 + k], lo[(size_t)i * 256 + k]);
+            host_split_bf16(cv, hi[(size_t)i * 256 + 128 + k], lo[(size_t)i * 256 + 128 + k]);
+        }
+    if (hipMemcpyAsync(m->sinp.hi, hi.data(), hi.size() * 2, hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipMemcpyAsync(m->sinp.lo, lo.data(), lo.size() * 2, hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess)
+        return fail(-6, "time table upload");
+    GemmArgs g1 = gemm_base(m->sinp, 256, m->time1, n_t);
+    g1.act = ACT_SILU; g1.out_hi = m->t1.hi; g1.out_lo = m->t1.lo; g1.ldob = D;
+    int r = run_gemm(m, g1, m->time1, EPI_GENERIC, false, 128, st, 128);
+    GemmArgs g2 = gemm_base(m->t1, D, m->time2, n_t);
+    g2.act = ACT_SILU; g2.out_hi = m->st.hi; g2.out_lo = m->st.lo; g2.ldob = D;   // silu(t_emb): the only form AdaLN consumes
+    if (!r) r = run_gemm(m, g2, m->time2, EPI_GENERIC, false, 128, st, 128);
+    GemmArgs g3 = gemm_base(m->st, D, m->adaln, n_t);
+    g3.out_f32 = m->mod; g3.ldo = m->n_adaln;
+    if (!r) r = run_gemm(m, g3, m->adaln, EPI_GENERIC, false, 128, st, 128);
+    return r;
+}
+
+// One DiT evaluation at time index ti for all laid-out sequences.  xs (split bf16 of x) must be current.
+// n_blocks < 0: full network, result in m->pred [M][128];  else stops after n_blocks blocks, result in m->h.
+static int forward_step(f5hip_dit* m, int ti, int n_blocks, hipStream_t st) {
+    const f5hip_dit_config& c = m->cfg;
+    const int D = c.dim, F = c.ff_mult * D, M = m->M;
+    const float* mod = m->mod + (size_t)ti * m->n_adaln;
+    // input projection: x part + precomputed cond/text part
+    GemmArgs gi = gemm_base(m->xs, 128, m->wx, M);
+    gi.bias = nullptr; gi.res = m->ce; gi.ldres = D; gi.out_f32 = m->h0; gi.ldo = D;
+    gi.out_hi = m->hn.hi; gi.out_lo = m->hn.lo; gi.ldob = D;
+    CK(run_gemm(m, gi, m->wx, EPI_GENERIC, false, 128, st));
+    // conv_pos_embed: Mish(GConv(Mish(GConv(h0)))) + h0   (F/model/modules.py:171-176, F/model/backbones/dit.py:86)
+    GemmArgs c1 = gemm_base(m->hn, D, m->conv1, M);
+    c1.conv_kpt = 2; c1.conv_center = 15; c1.conv_group_cols = m->gw; c1.row_seq_start = m->d_row_start; c1.row_seq_end = m->d_row_end;
+    c1.group_w = m->gw; c1.N = 16 * 64;
+    c1.act = ACT_MISH; c1.out_hi = m->c1.hi; c1.out_lo = m->c1.lo; c1.ldob = D;
+    CK(run_gemm(m, c1, m->conv1, EPI_GENERIC, true, 64, st));
+    GemmArgs c2 = gemm_base(m->c1, D, m->conv2, M);
+    c2.conv_kpt = 2; c2.conv_center = 15; c2.conv_group_cols = m->gw; c2.row_seq_start = m->d_row_start; c2.row_seq_end = m->d_row_end;
+    c2.group_w = m->gw; c2.N = 16 * 64;
+    c2.act = ACT_MISH; c2.res = m->h0; c2.ldres = D; c2.out_f32 = m->h; c2.ldo = D;
+    CK(run_gemm(m, c2, m->conv2, EPI_GENERIC, true, 64, st));
+
+    const int nb = n_blocks < 0 ? c.depth : n_blocks;
+    for (int l = 0; l < nb; l++) {
+        const float* ml = mod + (size_t)l * 6 * D;   // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
+        LnArgs ln; memset(&ln, 0, sizeof(ln));
+        ln.x = m->h; ln.ldx = D; ln.M = M; ln.D = D; ln.shift = ml; ln.scale = ml + D; ln.gain_off = 1.0f; ln.eps = 1e-6f;
+        ln.out_hi = m->hn.hi; ln.out_lo = m->hn.lo; ln.ldo = D;
+        CK(run_ln(ln, st));
+        GemmArgs q = gemm_base(m->hn, D, m->wqkv[l], M);
+        q.D = D; q.row_pos = m->d_row_pos; q.rope_cos = m->rope_cos; q.rope_sin = m->rope_sin; q.qk = m->qk; q.vt = m->vt; q.ldvt = m->M_pad;
+        CK(run_gemm(m, q, m->wqkv[l], EPI_QKV, false, 128, st));
+        AttnArgs at;
+        at.qk = m->qk; at.vt = m->vt; at.D = D; at.ldvt = m->M_pad; at.seq_row0 = m->d_seq_row0; at.seq_len = m->d_seq_len;
+        at.seq_kvlen = m->d_seq_kvlen; at.out_hi = m->ao.hi; at.out_lo = m->nsplit == 2 ? m->ao.lo : nullptr;
+        prof_begin(PROF_ATTN, st);
+        hipLaunchKernelGGL(attn_fwd_kernel, dim3((m->max_len + 127) / 128, c.heads, m->n_seq), dim3(256), 0, st, at);
+        prof_end(PROF_ATTN, st);
+        CKL("attention");
+        GemmArgs o = gemm_base(m->ao, D, m->wout[l], M);
+        o.mul = ml + 2 * D; o.res = m->h; o.ldres = D; o.out_f32 = m->h; o.ldo = D;
+        o.row_keep = m->any_masked ? m->d_row_keep : nullptr;
+        CK(run_gemm(m, o, m->wout[l], EPI_GENERIC, false, 64, st));
+        ln.shift = ml + 3 * D; ln.scale = ml + 4 * D;
+        CK(run_ln(ln, st));
+        GemmArgs f1 = gemm_base(m->hn, D, m->wff1[l], M);
+        f1.act = ACT_GELU_TANH; f1.out_hi = m->ff.hi; f1.out_lo = m->ff.lo; f1.ldob = F;
+        CK(run_gemm(m, f1, m->wff1[l], EPI_GENERIC, false, 128, st));
+        GemmArgs f2 = gemm_base(m->ff, F, m->wff2[l], M);
+        f2.mul = ml + 5 * D; f2.res = m->h; f2.ldres = D; f2.out_f32 = m->h; f2.ldo = D;
+        CK(run_gemm(m, f2, m->wff2[l], EPI_GENERIC, false, 64, st));
+    }
+    if (n_blocks >= 0) return 0;
+    const float* mf = mod + (size_t)c.depth * 6 * D;   // (scale, shift): F/model/modules.py:308
+    LnArgs ln; memset(&ln, 0, sizeof(ln));
+    ln.x = m->h; ln.ldx = D; ln.M = M; ln.D = D; ln.scale = mf; ln.shift = mf + D; ln.gain_off = 1.0f; ln.eps = 1e-6f;
+    ln.out_hi = m->hn.hi; ln.out_lo = m->hn.lo; ln.ldo = D;
+    CK(run_ln(ln, st));
+    GemmArgs po = gemm_base(m->hn, D, m->proj_out, M);
+    po.out_f32 = m->pred; po.ldo = 128;
+    CK(run_gemm(m, po, m->proj_out, EPI_GENERIC, false, 128, st));
+    return 0;
+}
+
+// -------------------------------------------------------------------------------------------------
+// public entry points
+// -------------------------------------------------------------------------------------------------
+int f5hip_dit_forward(f5hip_dit* m, int32_t n_seq, const int32_t* seq_len, const int32_t* kv_len, const float* x_dev,
+                      const float* cond_dev, const int32_t* text, int32_t nt_max, float time, const uint8_t* drop_audio_cond,
+                      const uint8_t* drop_text, int32_t n_blocks, float* out_dev, float* h_out_dev, void* stream) {
+    if (!m || !m->finalized) return fail(-1, "model not finalized");
+    if (n_seq <= 0 || !seq_len || !x_dev || !cond_dev || !text) return fail(-1, "dit_forward: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<SeqDesc> seqs(n_seq);
+    std::vector<int> frame_row;
+    int f0 = 0, r0 = 0;
+    m->h_seq_len.assign(n_seq, 0);
+    for (int i = 0; i < n_seq; i++) {
+        if (seq_len[i] <= 0 || seq_len[i] > 4096) return fail(-1, "seq_len[%d] = %d out of range", i, seq_len[i]);
+        seqs[i] = {seq_len[i], kv_len ? kv_len[i] : seq_len[i], f0, i, drop_audio_cond ? drop_audio_cond[i] : 0, drop_text ? drop_text[i] : 0};
+        if (seqs[i].kvlen <= 0 || seqs[i].kvlen > seqs[i].len) return fail(-1, "kv_len[%d] out of range", i);
+        m->h_seq_len[i] = seq_len[i];
+        for (int k = 0; k < seq_len[i]; k++) frame_row.push_back(r0 + k);
+        f0 += seq_len[i];
+        r0 += ceil_to(seq_len[i], 128);
+    }
+    CK(setup_sequences(m, seqs, f0, text, nt_max, nullptr, frame_row, {}, st));
+    const int M = m->M, mel = m->cfg.mel_dim, D = m->cfg.dim;
+    hipLaunchKernelGGL(split_rows_kernel, dim3(M), dim3(256), 0, st, x_dev, mel, mel, M, m->d_row_frame, m->xs.hi, m->xs.lo, 128, 0);
+    CKL("split x");
+    CK(precompute_text_and_ce(m, cond_dev, st));
+    CK(precompute_time(m, &time, 1, st));
+    CK(forward_step(m, 0, n_blocks, st));
+    // gather rows back to the caller's packed frame order
+    if (n_blocks < 0) {
+        if (!out_dev) return fail(-1, "out_dev is null");
+        hipLaunchKernelGGL(gather_rows_kernel, dim3(f0), dim3(128), 0, st, m->pred, 128, mel, f0, m->d_urow_c, out_dev, mel);
+    } else {
+        if (!h_out_dev) return fail(-1, "h_out_dev is null");
+        hipLaunchKernelGGL(gather_rows_kernel, dim3(f0), dim3(128), 0, st, m->h, D, D, f0, m->d_urow_c, h_out_dev, D);
+    }
+    CKL("gather rows");
+    return 0;
+}
+
+int f5hip_dit_read_tap(f5hip_dit* m, const char* tap, float* dst_dev, int64_t numel, void* stream) {
+    if (!m || !tap || !dst_dev) return fail(-1, "read_tap: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    if (!strcmp(tap, "text_embed")) {
+        const int Td = m->cfg.text_dim;
+        if (numel != (int64_t)m->n_frames * Td) return fail(-1, "read_tap: numel mismatch");
+        hipLaunchKernelGGL(gather_rows_kernel, dim3(m->n_frames), dim3(128), 0, st, m->te, Td, Td, m->n_frames, m->d_urow_c, dst_dev, Td);
+        CKL("gather tap");
+        return 0;
+    }
+    return fail(-1, "unknown tap %s", tap);
+}
+
+int f5hip_cfm_sample(f5hip_dit* m, int32_t n_utt, const int32_t* dur, const float* cond_dev, const uint8_t* cond_mask,
+                     const int32_t* text, int32_t nt_max, const float* y0_dev, const float* t_grid, int32_t steps,
+                     float cfg_strength, float* out_dev, void* stream) {
+    if (!m || !m->finalized) return fail(-1, "model not finalized");
+    if (n_utt <= 0 || !dur || !cond_dev || !cond_mask || !text || !y0_dev || !t_grid || !out_dev || steps <= 0)
+        return fail(-1, "cfm_sample: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    const bool use_cfg = !(cfg_strength < 1e-5f);
+    const int mel = m->cfg.mel_dim;
+    std::vector<SeqDesc> seqs;
+    std::vector<int> urow_c, urow_u;
+    int f0 = 0, r0 = 0;
+    m->h_seq_len.clear();
+    for (int u = 0; u < n_utt; u++) {
+        if (dur[u] <= 0 || dur[u] > 4096) return fail(-1, "dur[%d] = %d out of range", u, dur[u]);
+        seqs.push_back({dur[u], dur[u], f0, u, 0, 0});
+        m->h_seq_len.push_back(dur[u]);
+        const int rc = r0; r0 += ceil_to(dur[u], 128);
+        int ru = -1;
+        if (use_cfg) {
+            seqs.push_back({dur[u], dur[u], f0, u, 1, 1});
+            m->h_seq_len.push_back(dur[u]);
+            ru = r0; r0 += ceil_to(dur[u], 128);
+        }
+        for (int i = 0; i < dur[u]; i++) { urow_c.push_back(rc + i); urow_u.push_back(ru < 0 ? -1 : ru + i); }
+        f0 += dur[u];
+    }
+    CK(setup_sequences(m, seqs, f0, text, nt_max, cond_mask, urow_c, urow_u, st));
+    const int M = m->M;
+    if (hipMemcpyAsync(m->xstate, y0_dev, sizeof(float) * (size_t)f0 * mel, hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return fail(-6, "y0 copy");
+    hipLaunchKernelGGL(split_rows_kernel, dim3(M), dim3(256), 0, st, m->xstate, mel, mel, M, m->d_row_frame, m->xs.hi, m->xs.lo, 128, 0);
+    CKL("split x");
+    CK(precompute_text_and_ce(m, cond_dev, st));
+    CK(precompute_time(m, t_grid, steps, st));
+    for (int i = 0; i < steps; i++) {
+        CK(forward_step(m, i, -1, st));
+        prof_begin(PROF_OTHER, st);
+        hipLaunchKernelGGL(cfg_euler_kernel, dim3(f0), dim3(128), 0, st, m->xstate, mel, f0, m->pred, 128, m->d_urow_c, m->d_urow_u,
+                           cfg_strength, t_grid[i + 1] - t_grid[i], m->xs.hi, m->xs.lo, 128);
+        prof_end(PROF_OTHER, st);
+        CKL("cfg_euler");
+    }
+    hipLaunchKernelGGL(final_select_kernel, dim3(f0), dim3(128), 0, st, m->xstate, cond_dev, m->d_frame_is_cond, mel, f0, out_dev);
+    CKL("final_select");
+    return 0;
+}
+
+#include "vocos.h"

@@ -1,0 +1,156 @@
+// Host-side plumbing of libf5hip: error reporting, device allocations, weight packing, HIP-event profiling.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include <string.h>
+
+#include "common.h"
+#include "elementwise.h"
+
+// ---------------------------------------------------------------- errors
+static thread_local char g_err[512] = "";
+static void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+extern "C" const char* f5hip_last_error(void) { return g_err; }
+extern "C" int f5hip_abi_version(void) { return 1; }
+
+// ---------------------------------------------------------------- device memory
+struct Plane2 { __bf16* hi = nullptr; __bf16* lo = nullptr; };
+struct DevBuf { void* ptr = nullptr; };
+struct PackedW {
+    __bf16* hi = nullptr; __bf16* lo = nullptr; float* bias = nullptr;
+    int n = 0, k = 0, n_pad = 0, k_pad = 0;
+};
+
+template <typename T> static void dev_free(T* p) { if (p) (void)hipFree((void*)p); }
+
+// bump allocator over one hipMalloc'ed arena (256-byte aligned carves); base == nullptr only measures
+struct Arena {
+    char* base = nullptr; size_t off = 0;
+    void reset(char* b) { base = b; off = 0; }
+    void* take(size_t bytes) {
+        void* p = base ? base + off : nullptr;
+        off += (bytes + 255) / 256 * 256;
+        return p;
+    }
+    float* f32(size_t n) { return (float*)take(n * 4); }
+    __bf16* bf16(size_t n) { return (__bf16*)take(n * 2); }
+    Plane2 plane2(size_t n) { Plane2 p; p.hi = bf16(n); p.lo = bf16(n); return p; }
+    size_t used() const { return off; }
+};
+
+static int upload_f32(float** dst, const float* src, size_t n) {
+    if (hipMalloc((void**)dst, n * sizeof(float)) != hipSuccess) { *dst = nullptr; return fail(-4, "hipMalloc %zu floats", n); }
+    if (hipMemcpy(*dst, src, n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return fail(-4, "hipMemcpy H2D");
+    return 0;
+}
+
+// round-to-nearest-even fp32 -> bf16 on the host (finite inputs)
+static uint16_t host_bf16(float x) {
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+static float host_bf16_to_f32(uint16_t h) {
+    uint32_t u = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+static void host_split_bf16(float x, uint16_t& hi, uint16_t& lo) {
+    hi = host_bf16(x);
+    lo = host_bf16(x - host_bf16_to_f32(hi));
+}
+
+// W [N][K] fp32 host (row stride ldw) -> split bf16 device [ceil128(N)][ceil32(K)], bias -> fp32 [ceil128(N)]
+static int pack_linear(PackedW& out, const float* w, int N, int K, int ldw, const float* bias) {
+    out.n = N; out.k = K; out.n_pad = (N + 127) / 128 * 128; out.k_pad = (K + 31) / 32 * 32;
+    const size_t np = (size_t)out.n_pad * out.k_pad;
+    float* tmp = nullptr;
+    if (hipMalloc((void**)&tmp, (size_t)N * ldw * sizeof(float)) != hipSuccess) return fail(-4, "hipMalloc pack staging");
+    if (hipMalloc((void**)&out.hi, np * 2) != hipSuccess || hipMalloc((void**)&out.lo, np * 2) != hipSuccess) {
+        dev_free(tmp);
+        return fail(-4, "hipMalloc packed weight %d x %d", out.n_pad, out.k_pad);
+    }
+    if (hipMemcpy(tmp, w, (size_t)N * ldw * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { dev_free(tmp); return fail(-4, "H2D weight"); }
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(out.n_pad), dim3(256), 0, 0, tmp, N, K, ldw, out.hi, out.lo, out.k_pad);
+    if (hipDeviceSynchronize() != hipSuccess) { dev_free(tmp); return fail(-4, "pack_weight_kernel"); }
+    dev_free(tmp);
+    std::vector<float> b(out.n_pad, 0.0f);
+    if (bias) std::copy(bias, bias + N, b.begin());
+    return upload_f32(&out.bias, b.data(), b.size());
+}
+
+// ---------------------------------------------------------------- HIP-event profiling per kernel class
+enum { PROF_GEMM = 0, PROF_ATTN = 1, PROF_LN = 2, PROF_OTHER = 3, PROF_VOCOS = 4, PROF_N = 5 };
+static const char* g_prof_names[PROF_N] = {"gemm", "attn", "ln", "other", "vocos"};
+struct ProfSpan { int cls; hipEvent_t a, b; };
+static bool g_prof_on = false;
+static std::vector<ProfSpan> g_prof_spans;
+static std::vector<hipEvent_t> g_prof_pool;
+static double g_prof_ms[PROF_N];
+static long long g_prof_cnt[PROF_N];
+static int g_prof_open = 0;
+
+static hipEvent_t prof_event() {
+    if (!g_prof_pool.empty()) { hipEvent_t e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+static void prof_begin(int cls, hipStream_t st) {
+    if (!g_prof_on) return;
+    if (g_prof_open++) return;   // nested spans are attributed to the outer class
+    ProfSpan s; s.cls = cls; s.a = prof_event(); s.b = prof_event();
+    (void)hipEventRecord(s.a, st);
+    g_prof_spans.push_back(s);
+}
+static void prof_end(int cls, hipStream_t st) {
+    (void)cls;
+    if (!g_prof_on) return;
+    if (--g_prof_open) return;
+    (void)hipEventRecord(g_prof_spans.back().b, st);
+}
+static void prof_collect() {
+    for (auto& s : g_prof_spans) {
+        float ms = 0.0f;
+        (void)hipEventSynchronize(s.b);
+        if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) { g_prof_ms[s.cls] += ms; g_prof_cnt[s.cls]++; }
+        g_prof_pool.push_back(s.a); g_prof_pool.push_back(s.b);
+    }
+    g_prof_spans.clear();
+}
+extern "C" int f5hip_set_profiling(int32_t enabled) {
+    prof_collect();
+    g_prof_on = enabled != 0;
+    for (int i = 0; i < PROF_N; i++) { g_prof_ms[i] = 0.0; g_prof_cnt[i] = 0; }
+    return 0;
+}
+extern "C" int f5hip_get_profile(const char* kernel_class, double* total_ms, int64_t* launches) {
+    prof_collect();
+    for (int i = 0; i < PROF_N; i++)
+        if (!strcmp(kernel_class, g_prof_names[i])) {
+            if (total_ms) *total_ms = g_prof_ms[i];
+            if (launches) *launches = g_prof_cnt[i];
+            return 0;
+        }
+    return fail(-1, "unknown kernel class %s", kernel_class);
+}

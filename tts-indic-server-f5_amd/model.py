@@ -1,0 +1,184 @@
+"""Host-side mirror of the reference's model objects for the inference path.
+
+`F5HipModel` stands where the reference passes `model_obj` (a `CFM` wrapping a `DiT`):
+`sample()` has the signature and semantics of `CFM.sample` (F/model/cfm.py:82-210) and
+`transformer_forward()` those of `DiT.forward` (F/model/backbones/dit.py:130-163).  All arithmetic runs in
+libf5hip (HIP kernels); torch is used only to own device buffers and the stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import _lib
+from .tokenizer import list_str_to_idx
+
+
+@dataclass(frozen=True)
+class DiTArch:
+    """model.arch of F/configs/F5TTS_*_train.yaml:24-30."""
+    dim: int = 1024
+    depth: int = 22
+    heads: int = 16
+    ff_mult: int = 2
+    text_dim: int = 512
+    conv_layers: int = 4
+    mel_dim: int = 100
+    text_num_embeds: int = 2545
+
+
+F5TTS_BASE = DiTArch()
+F5TTS_SMALL = DiTArch(dim=768, depth=18, heads=12)
+
+
+def _i32(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.int32))
+
+
+def _ptr(t):
+    if isinstance(t, np.ndarray):
+        return C.c_void_p(t.ctypes.data)
+    return C.c_void_p(t.data_ptr())
+
+
+class F5HipModel:
+    def __init__(self, arch: DiTArch, state_dict: dict, vocab_char_map: dict | None = None, gemm_planes: int = 2,
+                 device: str | torch.device = "cuda:0", mel_spec_type: str = "vocos"):
+        self.arch = arch
+        self.device = torch.device(device)
+        self.vocab_char_map = vocab_char_map
+        self.mel_spec_type = mel_spec_type
+        self.num_channels = arch.mel_dim
+        self.gemm_planes = gemm_planes
+        self._lib = _lib.lib()
+        if self.device.type != "cuda":
+            raise _lib.F5HipError("F5HipModel needs a HIP device (no CPU fallback)")
+        torch.cuda.set_device(self.device)
+        cfg = _lib.DitConfig(arch.dim, arch.depth, arch.heads, arch.ff_mult, arch.text_dim, arch.conv_layers,
+                             arch.mel_dim, arch.text_num_embeds, gemm_planes)
+        self._h = self._lib.f5hip_dit_create(C.byref(cfg))
+        if not self._h:
+            raise _lib.F5HipError("f5hip_dit_create: " + self._lib.f5hip_last_error().decode())
+        # reference checkpoint keys: strip the EMA prefix like load_checkpoint does (F/infer/utils_infer.py:198-202)
+        for k, v in state_dict.items():
+            k = k.replace("ema_model.", "")
+            if not k.startswith("transformer."):
+                continue
+            a = np.ascontiguousarray(v.detach().to(torch.float32).cpu().numpy())
+            _lib.check(self._lib.f5hip_dit_load_param(self._h, k.encode(), _ptr(a), a.size), "load_param " + k)
+        _lib.check(self._lib.f5hip_dit_finalize(self._h), "f5hip_dit_finalize")
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.f5hip_dit_destroy(h)
+
+    def eval(self):
+        return self
+
+    # ------------------------------------------------------------------ DiT.forward
+    def transformer_forward(self, x, cond, text, time, drop_audio_cond, drop_text, mask=None, n_blocks=-1):
+        """DiT.forward for x/cond [b, n, mel] (device fp32), text int [b, nt], scalar time.  With `mask`
+        ([b, n] bool) the reference's padded-batch semantics are reproduced (key-padding + zeroed rows)."""
+        b, n, mel = x.shape
+        x = x.to(self.device, torch.float32).contiguous()
+        cond = cond.to(self.device, torch.float32).contiguous()
+        text = _i32(text.cpu().numpy() if isinstance(text, torch.Tensor) else text).reshape(b, -1)
+        seq_len = _i32([n] * b)
+        kv_len = _i32(mask.sum(-1).cpu().numpy()) if mask is not None else seq_len
+        da = np.full(b, 1 if drop_audio_cond else 0, dtype=np.uint8)
+        dt = np.full(b, 1 if drop_text else 0, dtype=np.uint8)
+        width = mel if n_blocks < 0 else self.arch.dim
+        out = torch.empty(b, n, width, device=self.device, dtype=torch.float32)
+        _lib.check(self._lib.f5hip_dit_forward(
+            self._h, b, _ptr(seq_len), _ptr(kv_len), _ptr(x), _ptr(cond), _ptr(text), text.shape[1], float(time),
+            _ptr(da), _ptr(dt), n_blocks, _ptr(out) if n_blocks < 0 else None, _ptr(out) if n_blocks >= 0 else None,
+            _lib.current_stream_ptr()), "f5hip_dit_forward")
+        return out
+
+    def read_tap(self, name: str, rows: int, width: int):
+        out = torch.empty(rows, width, device=self.device, dtype=torch.float32)
+        _lib.check(self._lib.f5hip_dit_read_tap(self._h, name.encode(), _ptr(out), out.numel(), _lib.current_stream_ptr()),
+                   "f5hip_dit_read_tap")
+        return out
+
+    # ------------------------------------------------------------------ CFM.sample
+    @torch.no_grad()
+    def sample(self, cond, text, duration, *, lens=None, steps=32, cfg_strength=1.0, sway_sampling_coef=None,
+               seed=None, max_duration=4096, vocoder=None, no_ref_audio=False, duplicate_test=False, t_inter=0.1,
+               edit_mask=None, y0=None):
+        """CFM.sample (F/model/cfm.py:82-210).  Returns (out [b, n, mel] on the device, None): the trajectory is
+        not materialised (its only in-tree consumer drops it, F/infer/utils_infer.py:459).
+
+        Every item of a batch is sampled with the reference's batch-1 semantics (mask=None, no padding), which
+        is what `infer_batch_process` uses; `y0` ([b, n, mel] or list of [dur_i, mel]) overrides the noise, which is
+        otherwise drawn exactly like the reference's CPU path (per item `torch.manual_seed(seed)`;
+        `torch.randn(dur, mel)` from the global CPU generator)."""
+        if duplicate_test:
+            raise NotImplementedError("duplicate_test is a debugging corner of the reference that is out of scope")
+        if cond.ndim == 2:   # raw wave -> mel (cfm.py:103-106)
+            from .mel import mel_spectrogram
+            cond = mel_spectrogram(cond.to(self.device, torch.float32)).permute(0, 2, 1)
+            assert cond.shape[-1] == self.num_channels
+        cond = cond.to(self.device, torch.float32)
+        batch, cond_seq_len = cond.shape[:2]
+        if lens is None:
+            lens = torch.full((batch,), cond_seq_len, dtype=torch.long)
+        lens = lens.cpu()
+        if isinstance(text, list):
+            assert self.vocab_char_map is not None, "string text needs a vocab_char_map"
+            text = list_str_to_idx(text, self.vocab_char_map)
+            assert text.shape[0] == batch
+        text = text.cpu()
+        text_lens = (text != -1).sum(dim=-1)
+        lens = torch.maximum(text_lens, lens)                                     # cfm.py:123-125
+        cond_mask = torch.arange(int(lens.amax()))[None, :] < lens[:, None]       # lens_to_mask
+        if edit_mask is not None:
+            cond_mask = cond_mask & edit_mask.cpu()
+        if isinstance(duration, int):
+            duration = torch.full((batch,), duration, dtype=torch.long)
+        duration = torch.maximum(lens + 1, duration.cpu()).clamp(max=max_duration)  # cfm.py:136-137
+        nmax = int(duration.amax())
+        cond = torch.nn.functional.pad(cond, (0, 0, 0, nmax - cond_seq_len), value=0.0)
+        cond_mask = torch.nn.functional.pad(cond_mask, (0, nmax - cond_mask.shape[-1]), value=False)
+
+        # noise (cfm.py:181-186)
+        if y0 is None:
+            ys = []
+            for dur in duration:
+                if seed is not None:
+                    torch.manual_seed(seed)
+                ys.append(torch.randn(int(dur), self.num_channels))
+        else:
+            ys = [y0[i][: int(duration[i])].cpu().float() for i in range(batch)]
+
+        t = torch.linspace(0, 1, steps + 1, dtype=torch.float32)                  # cfm.py:196-198
+        if sway_sampling_coef is not None:
+            t = t + sway_sampling_coef * (torch.cos(torch.pi / 2 * t) - 1 + t)
+
+        durs = [int(d) for d in duration]
+        cond_packed = torch.cat([cond[i, :durs[i]] for i in range(batch)], dim=0).contiguous()
+        mask_packed = np.ascontiguousarray(
+            torch.cat([cond_mask[i, :durs[i]] for i in range(batch)]).numpy().astype(np.uint8))
+        y0_packed = torch.cat(ys, dim=0).to(self.device).contiguous()
+        out_packed = torch.empty_like(y0_packed)
+        text_np = _i32(text.numpy())
+        tg = np.ascontiguousarray(t.numpy().astype(np.float32))
+        d_np = _i32(durs)
+        _lib.check(self._lib.f5hip_cfm_sample(
+            self._h, batch, _ptr(d_np), _ptr(cond_packed), _ptr(mask_packed), _ptr(text_np), text_np.shape[1],
+            _ptr(y0_packed), _ptr(tg), steps, float(cfg_strength), _ptr(out_packed), _lib.current_stream_ptr()),
+            "f5hip_cfm_sample")
+        out = torch.zeros(batch, nmax, self.num_channels, device=self.device, dtype=torch.float32)
+        o = 0
+        for i in range(batch):
+            out[i, :durs[i]] = out_packed[o:o + durs[i]]
+            o += durs[i]
+        if no_ref_audio:   # cfm.py:157-158: the final overwrite then copies zeros
+            out = torch.where(cond_mask[..., None].to(self.device), torch.zeros_like(out), out)
+        if vocoder is not None:
+            out = vocoder(out.permute(0, 2, 1))
+        return out, None
