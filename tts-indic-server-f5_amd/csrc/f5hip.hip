@@ -347,11 +347,12 @@ static GemmArgs gemm_base(const Plane2& A, int lda, const PackedW& W, int M) {
     return a;
 }
 
-static int run_gemm(f5hip_dit* m, GemmArgs& a, const PackedW& W, int epi, bool conv, int bn, hipStream_t st, int m_pad = -1) {
+static int run_gemm_n(int nsplit, int mp, GemmArgs& a, const PackedW& W, int epi, bool conv, int bn, hipStream_t st) {
     hipError_t e;
-    const int mp = m_pad > 0 ? m_pad : m->M_pad, np = W.n_pad;
+    const int np = W.n_pad;
+    if (mp % 128 || np % bn || a.K % 32) return fail(-7, "gemm: bad padded shape %d x %d x %d", mp, np, a.K);
     prof_begin(PROF_GEMM, st);
-    if (m->nsplit == 2) {
+    if (nsplit == 2) {
         if (epi == EPI_QKV) e = launch_gemm_t<2, 128, false, EPI_QKV>(a, mp, np, st);
         else if (conv && bn == 64) e = launch_gemm_t<2, 64, true, EPI_GENERIC>(a, mp, np, st);
         else if (conv) e = launch_gemm_t<2, 128, true, EPI_GENERIC>(a, mp, np, st);
@@ -367,6 +368,9 @@ static int run_gemm(f5hip_dit* m, GemmArgs& a, const PackedW& W, int epi, bool c
     prof_end(PROF_GEMM, st);
     if (e != hipSuccess) return fail(-7, "gemm launch: %s", hipGetErrorString(e));
     return 0;
+}
+static int run_gemm(f5hip_dit* m, GemmArgs& a, const PackedW& W, int epi, bool conv, int bn, hipStream_t st, int m_pad = -1) {
+    return run_gemm_n(m->nsplit, m_pad > 0 ? m_pad : m->M_pad, a, W, epi, conv, bn, st);
 }
 
 static int run_ln(const LnArgs& a, hipStream_t st) {

@@ -1,0 +1,54 @@
+"""Vocos vocoder object: stands where the reference passes `vocoder` (F/infer/utils_infer.py:92-115,472).
+
+`decode(mel[b, 100, T]) -> wave[b, 256 (T - 1)]` runs in libf5hip; state_dict keys are vocos 0.1.0's
+(`backbone.embed.weight`, `backbone.convnext.{i}.*`, `backbone.final_layer_norm.*`, `head.out.*`)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+class F5HipVocos:
+    def __init__(self, state_dict: dict, in_channels=100, dim=512, intermediate_dim=1536, num_layers=8, n_fft=1024,
+                 hop_length=256, gemm_planes: int = 2, device="cuda:0"):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.F5HipError("F5HipVocos needs a HIP device (no CPU fallback)")
+        torch.cuda.set_device(self.device)
+        self.hop_length = hop_length
+        self._lib = _lib.lib()
+        cfg = _lib.VocosConfig(in_channels, dim, intermediate_dim, num_layers, n_fft, hop_length, gemm_planes)
+        self._h = self._lib.f5hip_vocos_create(C.byref(cfg))
+        if not self._h:
+            raise _lib.F5HipError("f5hip_vocos_create: " + self._lib.f5hip_last_error().decode())
+        for k, v in state_dict.items():
+            if k.startswith("feature_extractor."):
+                continue   # mel front-end buffers of the checkpoint; decode() does not use them
+            a = np.ascontiguousarray(v.detach().to(torch.float32).cpu().numpy())
+            _lib.check(self._lib.f5hip_vocos_load_param(self._h, k.encode(), C.c_void_p(a.ctypes.data), a.size),
+                       "vocos load_param " + k)
+        _lib.check(self._lib.f5hip_vocos_finalize(self._h), "f5hip_vocos_finalize")
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.f5hip_vocos_destroy(h)
+
+    def eval(self):
+        return self
+
+    def to(self, device):
+        return self
+
+    @torch.no_grad()
+    def decode(self, mel: torch.Tensor) -> torch.Tensor:
+        b, c, t = mel.shape
+        mel = mel.to(self.device, torch.float32).contiguous()
+        wave = torch.empty(b, self.hop_length * (t - 1), device=self.device, dtype=torch.float32)
+        _lib.check(self._lib.f5hip_vocos_decode(self._h, b, t, C.c_void_p(mel.data_ptr()), C.c_void_p(wave.data_ptr()),
+                                                _lib.current_stream_ptr()), "f5hip_vocos_decode")
+        return wave
