@@ -205,7 +205,19 @@ def main():
     idx = torch.randperm(ob.numel(), generator=g)[:4096]
     save("dit_base_forward_digest", cond=cb.half(), idx=idx, sampled=ob.flatten()[idx],
          mean=ob.mean(), std=ob.std(), absmax=ob.abs().max())
-    del net_b
+    # ---- (4b) full CFM.sample at the C2 geometry (F5-Base, N = 1404, CFG 2, sway -1): digests at 4 and 32 NFE ----
+    cfm_b = cfm_mod.CFM(transformer=net_b, mel_spec_module=NoMel(), num_channels=100, odeint_kwargs=dict(method="euler")).eval()
+    gc = torch.Generator().manual_seed(14)
+    cond_b = torch.randn(1, 469, 100, generator=gc)
+    for steps in (4, 32):
+        out, _ = cfm_b.sample(cond=cond_b, text=tb, duration=1404, steps=steps, cfg_strength=2.0, sway_sampling_coef=-1.0,
+                              seed=synth.SEED_NOISE)
+        gen = out[0, 469:]
+        idx = torch.randperm(gen.numel(), generator=gc)[:16384]
+        save(f"cfm_base_sample_digest_s{steps}", idx=idx, sampled=gen.flatten()[idx], mean=gen.mean(), std=gen.std(),
+             absmax=gen.abs().max(), cond_head=out[0, :4])
+        print("base sample", steps, "done", flush=True)
+    del net_b, cfm_b
 
     # ---- (5) chunk_text / glue: reference's pure-python functions -----------------------
     gen_glue_fixtures()
