@@ -23,7 +23,7 @@ struct AttnArgs {
 
 F5_DEVICE int lds_off128(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_fwd_kernel(const AttnArgs p) {
     __shared__ __attribute__((aligned(16))) char smem[2 * 16384];
     const int seq = blockIdx.z, head = blockIdx.y;
     const int len = p.seq_len[seq], kvlen = p.seq_kvlen[seq], row0 = p.seq_row0[seq];
@@ -42,13 +42,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
     }
 
     const int nkt = (kvlen + 63) >> 6;
-    uint4 rk[2], rv[2];
+    u32x4 rk[2], rv[2];
     auto load_kv = [&](int kt) {
 #pragma unroll
         for (int i = 0; i < 2; i++) {
             const int idx = tid + 256 * i, r = idx >> 3, c = idx & 7;
-            rk[i] = *reinterpret_cast<const uint4*>(p.qk + (size_t)(row0 + kt * 64 + r) * (2 * D) + D + head * 64 + c * 8);
-            rv[i] = *reinterpret_cast<const uint4*>(p.vt + (size_t)(head * 64 + r) * p.ldvt + row0 + kt * 64 + c * 8);
+            rk[i] = *reinterpret_cast<const u32x4*>(p.qk + (size_t)(row0 + kt * 64 + r) * (2 * D) + D + head * 64 + c * 8);
+            rv[i] = *reinterpret_cast<const u32x4*>(p.vt + (size_t)(head * 64 + r) * p.ldvt + row0 + kt * 64 + c * 8);
         }
     };
     auto store_kv = [&](int stage) {
@@ -56,8 +56,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs p) {
 #pragma unroll
         for (int i = 0; i < 2; i++) {
             const int idx = tid + 256 * i, r = idx >> 3, c = idx & 7;
-            *reinterpret_cast<uint4*>(base + lds_off128(r, c)) = rk[i];
-            *reinterpret_cast<uint4*>(base + 8192 + lds_off128(r, c)) = rv[i];
+            *reinterpret_cast<u32x4*>(base + lds_off128(r, c)) = rk[i];
+            *reinterpret_cast<u32x4*>(base + 8192 + lds_off128(r, c)) = rv[i];
         }
     };
 

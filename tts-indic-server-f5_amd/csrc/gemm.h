@@ -55,7 +55,7 @@ struct GemmArgs {
 F5_DEVICE int lds_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
 
 template <int NSPLIT, int BN, bool CONV, int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_kernel(const GemmArgs p) {
     constexpr int BM = 128;
     constexpr int WAVES_N = BN / 64, WAVES_M = 4 / WAVES_N;
     constexpr int TM = BM / WAVES_M / 32, TN = 2;
@@ -70,8 +70,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
     const int lrow = tid >> 2, lchunk = tid & 3;
     const int nk = p.K >> 5;
 
-    int sstart[A_RPT], send[A_RPT];
-    if (CONV) {
+    int sstart[A_RPT] = {0}, send[A_RPT] = {0};
+    if constexpr (CONV) {
 #pragma unroll
         for (int i = 0; i < A_RPT; i++) {
             sstart[i] = p.row_seq_start[m0 + lrow + 64 * i];
@@ -80,45 +80,57 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
     }
     const int a_col0 = CONV ? (int)blockIdx.x * p.conv_group_cols : 0;
 
-    uint4 ra[NSPLIT][A_RPT], rb[NSPLIT][B_RPT];
-    auto load_tiles = [&](int kt) {
-        int a_col, shift = 0;
-        if (CONV) {
-            int tap = kt / p.conv_kpt;
-            a_col = a_col0 + (kt - tap * p.conv_kpt) * 32 + lchunk * 8;
-            shift = tap - p.conv_center;
-        } else {
-            a_col = kt * 32 + lchunk * 8;
-        }
+    // register staging of the next k-tile (kept in named registers: plain arrays + fully unrolled static indexing)
+    u32x4 ra[NSPLIT * A_RPT], rb[NSPLIT * B_RPT];
+    const __bf16* a_ptr[NSPLIT];
+    const __bf16* w_ptr[NSPLIT];
 #pragma unroll
-        for (int i = 0; i < A_RPT; i++) {
-            int src = m0 + lrow + 64 * i + shift;
-            bool ok = !CONV || (src >= sstart[i] && src < send[i]);
-#pragma unroll
-            for (int pl = 0; pl < NSPLIT; pl++) {
-                ra[pl][i] = ok ? *reinterpret_cast<const uint4*>(p.A[pl] + (size_t)src * p.lda + a_col)
-                               : make_uint4(0, 0, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < B_RPT; i++) {
-            size_t off = (size_t)(n0 + lrow + 64 * i) * p.K + kt * 32 + lchunk * 8;
-#pragma unroll
-            for (int pl = 0; pl < NSPLIT; pl++) rb[pl][i] = *reinterpret_cast<const uint4*>(p.W[pl] + off);
-        }
-    };
-    auto store_tiles = [&](int stage) {
-        char* base = smem + stage * STAGE;
-#pragma unroll
-        for (int pl = 0; pl < NSPLIT; pl++) {
-#pragma unroll
-            for (int i = 0; i < A_RPT; i++)
-                *reinterpret_cast<uint4*>(base + pl * A_PLANE + lds_off(lrow + 64 * i, lchunk)) = ra[pl][i];
-#pragma unroll
-            for (int i = 0; i < B_RPT; i++)
-                *reinterpret_cast<uint4*>(base + NSPLIT * A_PLANE + pl * B_PLANE + lds_off(lrow + 64 * i, lchunk)) = rb[pl][i];
-        }
-    };
+    for (int pl = 0; pl < NSPLIT; pl++) {
+        a_ptr[pl] = p.A[pl] + (size_t)(m0 + lrow) * p.lda + lchunk * 8 + a_col0;
+        w_ptr[pl] = p.W[pl] + (size_t)(n0 + lrow) * p.K + lchunk * 8;
+    }
+    const size_t a_row64 = (size_t)64 * p.lda, w_row64 = (size_t)64 * p.K;
+
+#define LOAD_TILES(KT)                                                                                         \
+    {                                                                                                          \
+        const int kt_ = (KT);                                                                                  \
+        int a_off_, shift_ = 0;                                                                                \
+        if constexpr (CONV) {                                                                                  \
+            const int tap_ = kt_ / p.conv_kpt;                                                                 \
+            a_off_ = (kt_ - tap_ * p.conv_kpt) * 32;                                                           \
+            shift_ = tap_ - p.conv_center;                                                                     \
+        } else {                                                                                               \
+            a_off_ = kt_ * 32;                                                                                 \
+        }                                                                                                      \
+        _Pragma("unroll") for (int i = 0; i < A_RPT; i++) {                                                    \
+            _Pragma("unroll") for (int pl = 0; pl < NSPLIT; pl++) {                                            \
+                if constexpr (CONV) {                                                                          \
+                    const int src_ = m0 + lrow + 64 * i + shift_;                                              \
+                    const bool ok_ = src_ >= sstart[i] && src_ < send[i];                                      \
+                    u32x4 v_ = {0u, 0u, 0u, 0u};                                                         \
+                    if (ok_) v_ = *reinterpret_cast<const u32x4*>(a_ptr[pl] + (ptrdiff_t)shift_ * p.lda + i * a_row64 + a_off_); \
+                    ra[pl * A_RPT + i] = v_;                                                                   \
+                } else {                                                                                       \
+                    ra[pl * A_RPT + i] = *reinterpret_cast<const u32x4*>(a_ptr[pl] + i * a_row64 + a_off_);    \
+                }                                                                                              \
+            }                                                                                                  \
+        }                                                                                                      \
+        _Pragma("unroll") for (int i = 0; i < B_RPT; i++) {                                                    \
+            _Pragma("unroll") for (int pl = 0; pl < NSPLIT; pl++)                                              \
+                rb[pl * B_RPT + i] = *reinterpret_cast<const u32x4*>(w_ptr[pl] + i * w_row64 + kt_ * 32);      \
+        }                                                                                                      \
+    }
+
+#define STORE_TILES(STG)                                                                                       \
+    {                                                                                                          \
+        char* base_ = smem + (STG) * STAGE;                                                                    \
+        _Pragma("unroll") for (int pl = 0; pl < NSPLIT; pl++) {                                                \
+            _Pragma("unroll") for (int i = 0; i < A_RPT; i++)                                                  \
+                *reinterpret_cast<u32x4*>(base_ + pl * A_PLANE + lds_off(lrow + 64 * i, lchunk)) = ra[pl * A_RPT + i]; \
+            _Pragma("unroll") for (int i = 0; i < B_RPT; i++)                                                  \
+                *reinterpret_cast<u32x4*>(base_ + NSPLIT * A_PLANE + pl * B_PLANE + lds_off(lrow + 64 * i, lchunk)) = rb[pl * B_RPT + i]; \
+        }                                                                                                      \
+    }
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -128,14 +140,14 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
 #pragma unroll
             for (int g = 0; g < 16; g++) acc[i][j][g] = 0.0f;
 
-    load_tiles(0);
-    store_tiles(0);
+    LOAD_TILES(0);
+    STORE_TILES(0);
     __syncthreads();
 
     const int fr = lane & 31, fh = lane >> 5;
     for (int kt = 0; kt < nk; kt++) {
         const bool more = kt + 1 < nk;
-        if (more) load_tiles(kt + 1);
+        if (more) LOAD_TILES(kt + 1);
         const char* base = smem + (kt & 1) * STAGE;
 #pragma unroll
         for (int s = 0; s < 2; s++) {
@@ -161,9 +173,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[0][j], acc[i][j], 0, 0, 0);
                 }
         }
-        if (more) store_tiles((kt + 1) & 1);
+        if (more) STORE_TILES((kt + 1) & 1);
         __syncthreads();
     }
+#undef LOAD_TILES
+#undef STORE_TILES
 
     // ---------------------------------------------------------------- epilogue
     // acc[i][j][g] = C[m][n], m = m0 + wm*TM*32 + i*32 + (g&3) + 8*(g>>2) + 4*fh, n = n0 + wn*64 + j*32 + fr
