@@ -54,7 +54,54 @@ struct GemmArgs {
 
 F5_DEVICE int lds_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
 
-template <int NSPLIT, int BN, bool CONV, int EPI>
+
+// Row-contiguous generic epilogue for one 32 x 64 wave sub-tile staged in LDS (fp32): each lane owns 4 columns of 8 rows.
+template <int ACT>
+F5_DEVICE void epi_generic_rows(const GemmArgs& p, const float* stg, int m_base, int n, int c4, int r0) {
+    int no = n;              // column in the output / residual / multiplier
+    bool nok = n < ((p.N + 3) & ~3);
+    if (p.group_w) {
+        nok = nok && (n & 63) < p.group_w;
+        no = (n >> 6) * p.group_w + (n & 63);
+    }
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f}, mv = {1.f, 1.f, 1.f, 1.f};
+    if (p.bias && nok) bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+    if (p.mul && nok) mv = *reinterpret_cast<const f32x4*>(p.mul + no);
+    f32x4 rs[8];
+    int keep[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        const int m = m_base + q * 4 + r0;
+        rs[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        keep[q] = 1;
+        if (p.res && nok && m < p.M) rs[q] = *reinterpret_cast<const f32x4*>(p.res + (size_t)m * p.ldres + no);
+        if (p.row_keep) keep[q] = p.row_keep[m];
+    }
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        const int m = m_base + q * 4 + r0;
+        f32x4 v = *reinterpret_cast<const f32x4*>(stg + (q * 4 + r0) * 64 + c4) + bv;
+        if (ACT != ACT_NONE) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[e] = apply_act(v[e], ACT);
+        }
+        if (!keep[q]) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+        v = v * mv + rs[q];
+        if (nok && m < p.M) {
+            if (p.out_f32) *reinterpret_cast<f32x4*>(p.out_f32 + (size_t)m * p.ldo + no) = v;
+            if (p.out_hi) {
+                bf16x4 hi, lo;
+                const float vv[4] = {v[0], v[1], v[2], v[3]};
+                split_bf16x4(vv, hi, lo);
+                *reinterpret_cast<bf16x4*>(p.out_hi + (size_t)m * p.ldob + no) = hi;
+                if (p.out_lo) *reinterpret_cast<bf16x4*>(p.out_lo + (size_t)m * p.ldob + no) = lo;
+            }
+        }
+    }
+}
+
+// ABL (diagnostics only, f5hip_debug_gemm_bench): 0 = normal, 1 = no global loads inside the k-loop, 2 = no LDS reads / MFMAs
+template <int NSPLIT, int BN, bool CONV, int EPI, int ABL = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_kernel(const GemmArgs p) {
     constexpr int BM = 128;
     constexpr int WAVES_N = BN / 64, WAVES_M = 4 / WAVES_N;
@@ -147,10 +194,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int fr = lane & 31, fh = lane >> 5;
     for (int kt = 0; kt < nk; kt++) {
         const bool more = kt + 1 < nk;
-        if (more) LOAD_TILES(kt + 1);
+        if (more && ABL != 1) LOAD_TILES(kt + 1);
         const char* base = smem + (kt & 1) * STAGE;
 #pragma unroll
-        for (int s = 0; s < 2; s++) {
+        for (int s = 0; s < (ABL == 2 ? 0 : 2); s++) {
             bf16x8 af[NSPLIT][TM], bf[NSPLIT][TN];
             const int chunk = s * 2 + fh;
 #pragma unroll
@@ -173,98 +220,102 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[0][j], acc[i][j], 0, 0, 0);
                 }
         }
-        if (more) STORE_TILES((kt + 1) & 1);
+        if (more && ABL != 1) STORE_TILES((kt + 1) & 1);
         __syncthreads();
     }
 #undef LOAD_TILES
 #undef STORE_TILES
 
     // ---------------------------------------------------------------- epilogue
-    // acc[i][j][g] = C[m][n], m = m0 + wm*TM*32 + i*32 + (g&3) + 8*(g>>2) + 4*fh, n = n0 + wn*64 + j*32 + fr
-    if (EPI == EPI_GENERIC) {
+    // acc[i][j][g] = C[m][n], m = m0 + wm*TM*32 + i*32 + (g&3) + 8*(g>>2) + 4*fh, n = n0 + wn*64 + j*32 + fr.
+    // Each wave transposes its 32 x 64 sub-tile through a private 8 KB LDS slab so that every lane owns 4 consecutive
+    // columns of a row: residual / output traffic becomes 16-byte (fp32) and 8-byte (bf16) row-contiguous accesses,
+    // all residual loads are issued before any arithmetic, and the rotary pairs of the QKV epilogue are lane-local.
+    float* stg = reinterpret_cast<float*>(smem) + wave * 2048;
+    const int n_base = n0 + wn * 64;
 #pragma unroll
-        for (int j = 0; j < TN; j++) {
-            const int n = n0 + wn * 64 + j * 32 + fr;   // column in the (possibly group-padded) weight layout
-            int no = n;                                  // column in the output / residual / multiplier
-            bool nok = n < p.N;
-            if (p.group_w) {
-                nok = nok && (n & 63) < p.group_w;
-                no = (n >> 6) * p.group_w + (n & 63);
-            }
-            const float bv = (p.bias && nok) ? p.bias[n] : 0.0f;
-            const float mv = (p.mul && nok) ? p.mul[no] : 1.0f;
+    for (int i = 0; i < TM; i++) {
+        const int m_base = m0 + wm * (TM * 32) + i * 32;
+        if (EPI == EPI_QKV && n0 >= 2 * p.D) {
+            // V block: written transposed ([feature][token]) straight from the accumulators, 4 tokens = 8 bytes per store
+            const int nd0 = n0 - 2 * p.D;
 #pragma unroll
-            for (int i = 0; i < TM; i++) {
+            for (int j = 0; j < TN; j++) {
+                const int nd = nd0 + wn * 64 + j * 32 + fr;
+                const float bv = p.bias[n_base + j * 32 + fr];
 #pragma unroll
-                for (int g = 0; g < 16; g++) {
-                    const int m = m0 + wm * (TM * 32) + i * 32 + (g & 3) + 8 * (g >> 2) + 4 * fh;
-                    if (nok && m < p.M) {
-                        float v = apply_act(acc[i][j][g] + bv, p.act);
-                        if (p.row_keep && !p.row_keep[m]) v = 0.0f;
-                        v *= mv;
-                        if (p.res) v += p.res[(size_t)m * p.ldres + no];
-                        if (p.out_f32) p.out_f32[(size_t)m * p.ldo + no] = v;
-                        if (p.out_hi) {
-                            __bf16 hi, lo;
-                            split_bf16(v, hi, lo);
-                            p.out_hi[(size_t)m * p.ldob + no] = hi;
-                            if (p.out_lo) p.out_lo[(size_t)m * p.ldob + no] = lo;
-                        }
-                    }
+                for (int a4 = 0; a4 < 4; a4++) {
+                    bf16x4 pk;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) pk[e] = (__bf16)(acc[i][j][a4 * 4 + e] + bv);
+                    *reinterpret_cast<bf16x4*>(p.vt + (size_t)nd * p.ldvt + m_base + 8 * a4 + 4 * fh) = pk;
                 }
             }
+            continue;
         }
-    } else {
-        const int D = p.D;
-        const int which = n0 / D;             // 0 q, 1 k, 2 v (uniform per workgroup: D % BN == 0)
-        const int nd0 = n0 - which * D;       // column offset inside the q/k/v block
+        __syncthreads();
 #pragma unroll
-        for (int j = 0; j < TN; j++) {
-            const int nd = nd0 + wn * 64 + j * 32 + fr;
-            const float bv = p.bias[n0 + wn * 64 + j * 32 + fr];
-            const bool rot = which < 2 && nd < 64;   // head 0 only (rotary applied before the head split)
+        for (int j = 0; j < TN; j++)
 #pragma unroll
-            for (int i = 0; i < TM; i++) {
-                if (which < 2) {
+            for (int g = 0; g < 16; g++) stg[((g & 3) + 8 * (g >> 2) + 4 * fh) * 64 + j * 32 + fr] = acc[i][j][g];
+        __syncthreads();
+        const int c4 = (lane & 15) * 4, r0 = lane >> 4;
+        const int n = n_base + c4;   // column in the (possibly group-padded) weight layout
+        if (EPI == EPI_GENERIC) {
+            switch (p.act) {
+                case ACT_GELU_TANH: epi_generic_rows<ACT_GELU_TANH>(p, stg, m_base, n, c4, r0); break;
+                case ACT_GELU_ERF: epi_generic_rows<ACT_GELU_ERF>(p, stg, m_base, n, c4, r0); break;
+                case ACT_MISH: epi_generic_rows<ACT_MISH>(p, stg, m_base, n, c4, r0); break;
+                case ACT_SILU: epi_generic_rows<ACT_SILU>(p, stg, m_base, n, c4, r0); break;
+                default: epi_generic_rows<ACT_NONE>(p, stg, m_base, n, c4, r0); break;
+            }
+        } else {
+            // Q / K blocks: bias, rotary embedding on head 0 (interleaved pairs, lane-local), q * 1/8, bf16 row-major
+            const int D = p.D;
+            const int which = n0 / D;        // 0 q, 1 k (uniform per workgroup: D % BN == 0)
+            const int nd = n - which * D;
+            const bool rot = nd < 64;        // head 0 only: rotary is applied before the head split
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+            int pos[8];
 #pragma unroll
-                    for (int g = 0; g < 16; g++) {
-                        const int m = m0 + wm * (TM * 32) + i * 32 + (g & 3) + 8 * (g >> 2) + 4 * fh;
-                        float v = acc[i][j][g] + bv;
-                        if (rot) {   // wave-uniform: nd < 64 for a whole 32-column fragment
-                            const float other = __shfl_xor(v, 1, 64);
-                            const int pos = p.row_pos[m];
-                            const float c = p.rope_cos[pos * 32 + (nd >> 1)], sn = p.rope_sin[pos * 32 + (nd >> 1)];
-                            v = (nd & 1) ? (v * c + other * sn) : (v * c - other * sn);
-                        }
-                        if (which == 0) v *= 0.125f;   // softmax scale 1/sqrt(64), exact in bf16
-                        if (m < p.M) p.qk[(size_t)m * (2 * D) + which * D + nd] = (__bf16)v;
-                    }
-                } else {
+            for (int q = 0; q < 8; q++) pos[q] = rot ? p.row_pos[m_base + q * 4 + r0] : 0;
+            float2 cs[8], sn[8];
 #pragma unroll
-                    for (int a = 0; a < 4; a++) {
-                        const int mb = m0 + wm * (TM * 32) + i * 32 + 8 * a + 4 * fh;
-                        bf16x4 pk;
-#pragma unroll
-                        for (int e = 0; e < 4; e++) pk[e] = (__bf16)(acc[i][j][a * 4 + e] + bv);
-                        *reinterpret_cast<bf16x4*>(p.vt + (size_t)nd * p.ldvt + mb) = pk;
-                    }
+            for (int q = 0; q < 8; q++) {
+                cs[q] = make_float2(1.f, 1.f);
+                sn[q] = make_float2(0.f, 0.f);
+                if (rot) {
+                    cs[q] = *reinterpret_cast<const float2*>(p.rope_cos + pos[q] * 32 + (nd >> 1));
+                    sn[q] = *reinterpret_cast<const float2*>(p.rope_sin + pos[q] * 32 + (nd >> 1));
                 }
+            }
+            const float qs = which == 0 ? 0.125f : 1.0f;   // softmax scale 1/sqrt(64), exact in bf16
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int m = m_base + q * 4 + r0;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(stg + (q * 4 + r0) * 64 + c4) + bv;
+                bf16x4 o;
+                o[0] = (__bf16)((v[0] * cs[q].x - v[1] * sn[q].x) * qs);
+                o[1] = (__bf16)((v[1] * cs[q].x + v[0] * sn[q].x) * qs);
+                o[2] = (__bf16)((v[2] * cs[q].y - v[3] * sn[q].y) * qs);
+                o[3] = (__bf16)((v[3] * cs[q].y + v[2] * sn[q].y) * qs);
+                if (m < p.M) *reinterpret_cast<bf16x4*>(p.qk + (size_t)m * (2 * D) + which * D + nd) = o;
             }
         }
     }
 }
 
-template <int NSPLIT, int BN, bool CONV, int EPI>
+template <int NSPLIT, int BN, bool CONV, int EPI, int ABL = 0>
 static hipError_t launch_gemm_t(const GemmArgs& a, int m_pad, int n_pad, hipStream_t st) {
-    constexpr int LDS = 2 * NSPLIT * (128 + BN) * 64;
+    constexpr int LDS = 2 * NSPLIT * (128 + BN) * 64 < 32768 ? 32768 : 2 * NSPLIT * (128 + BN) * 64;   // >= 4 x 8 KB epilogue slabs
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<NSPLIT, BN, CONV, EPI>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<NSPLIT, BN, CONV, EPI, ABL>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     dim3 grid(n_pad / BN, m_pad / 128);
-    hipLaunchKernelGGL((gemm_kernel<NSPLIT, BN, CONV, EPI>), grid, dim3(256), LDS, st, a);
+    hipLaunchKernelGGL((gemm_kernel<NSPLIT, BN, CONV, EPI, ABL>), grid, dim3(256), LDS, st, a);
     return hipGetLastError();
 }
