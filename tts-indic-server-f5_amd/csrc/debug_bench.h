@@ -11,27 +11,32 @@ __global__ void fill_pattern_kernel(float* x, size_t n, unsigned seed) {
 
 extern "C" int f5hip_debug_gemm_bench(int32_t M, int32_t N, int32_t K, int32_t planes, int32_t bn, int32_t variant, int32_t iters,
                                       double* avg_us) {
-    if (M % 128 || N % 128 || K % 32 || !avg_us) return fail(-1, "debug_gemm_bench: bad shape");
+    if (M % 256 || N % 128 || K % 32 || !avg_us) return fail(-1, "debug_gemm_bench: bad shape");
     float *fa = nullptr, *fw = nullptr, *outf = nullptr;
     Plane2 A, O; PackedW W;
-    size_t na = (size_t)M * K, nw = (size_t)N * K, no = (size_t)M * N;
+    const int pad = variant >= 100 ? 64 : 0;   // +128 B per row: breaks the power-of-two row stride
+    if (variant >= 100) variant -= 100;
+    const int lda = K + pad, ldw = K + pad;
+    size_t na = (size_t)M * lda, nw = (size_t)N * ldw, no = (size_t)M * N;
     if (hipMalloc(&fa, na * 4) || hipMalloc(&fw, nw * 4) || hipMalloc(&outf, no * 4) || hipMalloc(&A.hi, na * 2) || hipMalloc(&A.lo, na * 2) ||
         hipMalloc(&O.hi, no * 2) || hipMalloc(&O.lo, no * 2) || hipMalloc(&W.hi, nw * 2) || hipMalloc(&W.lo, nw * 2))
         return fail(-5, "debug_gemm_bench: hipMalloc");
     hipLaunchKernelGGL(fill_pattern_kernel, dim3((na + 255) / 256), dim3(256), 0, 0, fa, na, 1u);
     hipLaunchKernelGGL(fill_pattern_kernel, dim3((nw + 255) / 256), dim3(256), 0, 0, fw, nw, 2u);
-    hipLaunchKernelGGL(pack_weight_kernel, dim3(M), dim3(256), 0, 0, fa, M, K, K, A.hi, A.lo, K);
-    hipLaunchKernelGGL(pack_weight_kernel, dim3(N), dim3(256), 0, 0, fw, N, K, K, W.hi, W.lo, K);
-    W.n = N; W.k = K; W.n_pad = N; W.k_pad = K; W.bias = nullptr;
-    GemmArgs a = gemm_base(A, K, W, M);
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(M), dim3(256), 0, 0, fa, M, K, K, A.hi, A.lo, lda);
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(N), dim3(256), 0, 0, fw, N, K, K, W.hi, W.lo, ldw);
+    W.n = N; W.k = K; W.n_pad = N; W.k_pad = K; W.ld = ldw; W.bias = nullptr;
+    GemmArgs a = gemm_base(A, lda, W, M);
     a.act = ACT_GELU_TANH; a.out_hi = O.hi; a.out_lo = O.lo; a.ldob = N;
-    if (variant >= 10) { a.act = ACT_NONE; a.out_hi = nullptr; a.out_lo = nullptr; a.res = outf; a.ldres = N; a.out_f32 = outf; a.ldo = N; variant -= 10; }
+    if (variant >= 10 && variant < 20) { a.act = ACT_NONE; a.out_hi = nullptr; a.out_lo = nullptr; a.res = outf; a.ldres = N; a.out_f32 = outf; a.ldo = N; variant -= 10; }
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     hipError_t e = hipSuccess;
     for (int it = -2; it < iters; it++) {
         if (it == 0) hipEventRecord(e0, 0);
-        if (planes == 2 && bn == 128) {
+        if (variant == 20) e = planes == 2 ? launch_gemm2_t<2, 128, 128, EPI_GENERIC>(a, M, N, 0) : launch_gemm2_t<1, 128, 128, EPI_GENERIC>(a, M, N, 0);
+        else if (variant == 21) e = planes == 2 ? launch_gemm2_t<2, 256, 128, EPI_GENERIC>(a, M, N, 0) : launch_gemm2_t<1, 256, 128, EPI_GENERIC>(a, M, N, 0);
+        else if (planes == 2 && bn == 128) {
             if (variant == 0) e = launch_gemm_t<2, 128, false, EPI_GENERIC, 0>(a, M, N, 0);
             else if (variant == 1) e = launch_gemm_t<2, 128, false, EPI_GENERIC, 1>(a, M, N, 0);
             else e = launch_gemm_t<2, 128, false, EPI_GENERIC, 2>(a, M, N, 0);

@@ -4,6 +4,7 @@
 
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <map>
@@ -14,6 +15,7 @@
 #include "common.h"
 #include "elementwise.h"
 #include "gemm.h"
+#include "gemm2.h"
 #include "host_util.h"
 
 // =================================================================================================
@@ -342,17 +344,39 @@ static GemmArgs gemm_base(const Plane2& A, int lda, const PackedW& W, int M) {
     memset(&a, 0, sizeof(a));
     a.A[0] = A.hi; a.A[1] = A.lo; a.lda = lda;
     a.W[0] = W.hi; a.W[1] = W.lo;
-    a.M = M; a.N = W.n; a.K = W.k_pad;
+    a.M = M; a.N = W.n; a.K = W.k_pad; a.ldw = W.ld;
     a.bias = W.bias;
     return a;
 }
+
+static int g_gemm_impl = -1;   // 0 = automatic, 1 = register-staged 4-wave kernel only (gemm.h), 2 = LDS-DMA ring kernel wherever applicable (gemm2.h)
 
 static int run_gemm_n(int nsplit, int mp, GemmArgs& a, const PackedW& W, int epi, bool conv, int bn, hipStream_t st) {
     hipError_t e;
     const int np = W.n_pad;
     if (mp % 128 || np % bn || a.K % 32) return fail(-7, "gemm: bad padded shape %d x %d x %d", mp, np, a.K);
+    if (g_gemm_impl < 0) {
+        const char* env = getenv("F5HIP_GEMM_IMPL");
+        g_gemm_impl = env ? atoi(env) : 0;   // 0 = automatic
+    }
     prof_begin(PROF_GEMM, st);
-    if (nsplit == 2) {
+    // Kernel choice (tools/gemm_microbench.py + rocprof, MI355X): with at most one 128 x 128 tile per CU the 8-wave LDS-DMA
+    // kernel finishes a tile ~1.3x sooner than the 4-wave register-staged one; with more tiles than CUs two co-resident
+    // 4-wave workgroups hide each other's prologue / epilogue and win.  F5HIP_GEMM_IMPL=1 / 2 forces one kernel.
+    const long long tiles128 = (long long)(mp / 128) * (np / 128);
+    const bool use2 = !conv && (g_gemm_impl == 2 || (g_gemm_impl == 0 && tiles128 <= 256 && epi != EPI_QKV));
+    if (use2) {
+        const bool big = mp % 256 == 0 && tiles128 >= 4 * 256 && epi != EPI_QKV;
+        if (nsplit == 2) {
+            if (epi == EPI_QKV) e = launch_gemm2_t<2, 128, 128, EPI_QKV>(a, mp, np, st);
+            else if (big) e = launch_gemm2_t<2, 256, 128, EPI_GENERIC>(a, mp, np, st);
+            else e = launch_gemm2_t<2, 128, 128, EPI_GENERIC>(a, mp, np, st);
+        } else {
+            if (epi == EPI_QKV) e = launch_gemm2_t<1, 128, 128, EPI_QKV>(a, mp, np, st);
+            else if (big) e = launch_gemm2_t<1, 256, 128, EPI_GENERIC>(a, mp, np, st);
+            else e = launch_gemm2_t<1, 128, 128, EPI_GENERIC>(a, mp, np, st);
+        }
+    } else if (nsplit == 2) {
         if (epi == EPI_QKV) e = launch_gemm_t<2, 128, false, EPI_QKV>(a, mp, np, st);
         else if (conv && bn == 64) e = launch_gemm_t<2, 64, true, EPI_GENERIC>(a, mp, np, st);
         else if (conv) e = launch_gemm_t<2, 128, true, EPI_GENERIC>(a, mp, np, st);

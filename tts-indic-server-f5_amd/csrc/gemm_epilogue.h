@@ -1,0 +1,179 @@
+// Shared epilogue of the MFMA GEMM kernels (gemm.h, gemm2.h).
+//
+// A wave holds TM x TN accumulator tiles of 32 x 32 (v_mfma_f32_32x32x16_bf16 C/D layout: column on the lane,
+// rows (g&3) + 8 (g>>2) + 4 (lane>>5) in register g).  Each 32 x (32 TN) slice is transposed through a wave-private
+// LDS slab so that every lane owns 4 consecutive columns of a row: residual / output traffic becomes 16-byte (fp32)
+// and 8-byte (bf16) row-contiguous accesses, all residual loads are issued before any arithmetic, and the rotary
+// pairs of the QKV epilogue are lane-local.
+#pragma once
+#include "common.h"
+
+enum { EPI_GENERIC = 0, EPI_QKV = 1 };
+
+struct GemmArgs {
+    const __bf16* A[2];
+    int lda;
+    const __bf16* W[2];
+    int ldw;              // row stride of W in elements (>= K)
+    int M, N, K;
+    // implicit-GEMM conv (gemm.h only)
+    int conv_kpt;         // k-tiles (of 32 channels) per tap
+    int conv_center;      // (kernel_size - 1) / 2
+    int conv_group_cols;  // A column base = blockIdx.x * conv_group_cols (grouped conv with BN == group width)
+    const int* row_seq_start;
+    const int* row_seq_end;
+    int group_w;          // > 0: N is laid out as groups padded to 64 columns; real column = (n/64)*group_w + n%64
+    // generic epilogue: v = act(acc + bias); rows with row_keep == 0 -> 0; v = v * mul + res; store fp32 and/or split bf16
+    const float* bias;
+    const int* row_keep;
+    int act;
+    const float* mul;
+    const float* res;
+    int ldres;
+    float* out_f32;
+    int ldo;
+    __bf16* out_hi;
+    __bf16* out_lo;
+    int ldob;
+    // QKV epilogue
+    int D;                   // model dim (N == 3 D)
+    const int* row_pos;      // [M_pad] frame index inside the row's sequence
+    const float* rope_cos;   // [max_pos][32]
+    const float* rope_sin;
+    __bf16* qk;              // [M_pad][2 D]
+    __bf16* vt;              // [D][ldvt]
+    int ldvt;
+};
+
+// one 32 x WN slice staged in `stg` (fp32, row stride WN): generic epilogue, lane owns 4 columns of 32 / RPP rows
+template <int ACT, int WN>
+F5_DEVICE void epi_generic_rows(const GemmArgs& p, const float* stg, int m_base, int n_base, int lane) {
+    constexpr int LPR = WN / 4, RPP = 64 / LPR, NQ = 32 / RPP;
+    const int c4 = (lane % LPR) * 4, r0 = lane / LPR;
+    const int n = n_base + c4;   // column in the (possibly group-padded) weight layout
+    int no = n;                  // column in the output / residual / multiplier
+    bool nok = n < ((p.N + 3) & ~3);
+    if (p.group_w) {
+        nok = nok && (n & 63) < p.group_w;
+        no = (n >> 6) * p.group_w + (n & 63);
+    }
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f}, mv = {1.f, 1.f, 1.f, 1.f};
+    if (p.bias && nok) bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+    if (p.mul && nok) mv = *reinterpret_cast<const f32x4*>(p.mul + no);
+    f32x4 rs[NQ];
+    int keep[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+        const int m = m_base + q * RPP + r0;
+        rs[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        keep[q] = 1;
+        if (p.res && nok && m < p.M) rs[q] = *reinterpret_cast<const f32x4*>(p.res + (size_t)m * p.ldres + no);
+        if (p.row_keep) keep[q] = p.row_keep[m];
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+        const int m = m_base + q * RPP + r0;
+        f32x4 v = *reinterpret_cast<const f32x4*>(stg + (q * RPP + r0) * WN + c4) + bv;
+        if (ACT != ACT_NONE) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[e] = apply_act(v[e], ACT);
+        }
+        if (!keep[q]) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+        v = v * mv + rs[q];
+        if (nok && m < p.M) {
+            if (p.out_f32) *reinterpret_cast<f32x4*>(p.out_f32 + (size_t)m * p.ldo + no) = v;
+            if (p.out_hi) {
+                bf16x4 hi, lo;
+                const float vv[4] = {v[0], v[1], v[2], v[3]};
+                split_bf16x4(vv, hi, lo);
+                *reinterpret_cast<bf16x4*>(p.out_hi + (size_t)m * p.ldob + no) = hi;
+                if (p.out_lo) *reinterpret_cast<bf16x4*>(p.out_lo + (size_t)m * p.ldob + no) = lo;
+            }
+        }
+    }
+}
+
+// Q / K blocks of the fused QKV projection: bias, rotary embedding on head 0 (x-transformers interleaved pairs, applied
+// before the head split: F/model/modules.py:414-419), q * 1/8 (softmax scale, exact in bf16), bf16 row-major [M][2 D]
+template <int WN>
+F5_DEVICE void epi_qk_rows(const GemmArgs& p, const float* stg, int m_base, int n_base, int lane) {
+    constexpr int LPR = WN / 4, RPP = 64 / LPR, NQ = 32 / RPP;
+    const int c4 = (lane % LPR) * 4, r0 = lane / LPR;
+    const int n = n_base + c4;
+    const int D = p.D;
+    const int which = n_base / D;    // 0 q, 1 k (uniform per wave: D % 64 == 0)
+    const int nd = n - which * D;
+    const bool rot = nd < 64;        // head 0 only
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+    int pos[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) pos[q] = rot ? p.row_pos[m_base + q * RPP + r0] : 0;
+    float2 cs[NQ], sn[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+        cs[q] = make_float2(1.f, 1.f);
+        sn[q] = make_float2(0.f, 0.f);
+        if (rot) {
+            cs[q] = *reinterpret_cast<const float2*>(p.rope_cos + pos[q] * 32 + (nd >> 1));
+            sn[q] = *reinterpret_cast<const float2*>(p.rope_sin + pos[q] * 32 + (nd >> 1));
+        }
+    }
+    const float qs = which == 0 ? 0.125f : 1.0f;
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+        const int m = m_base + q * RPP + r0;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(stg + (q * RPP + r0) * WN + c4) + bv;
+        bf16x4 o;
+        o[0] = (__bf16)((v[0] * cs[q].x - v[1] * sn[q].x) * qs);
+        o[1] = (__bf16)((v[1] * cs[q].x + v[0] * sn[q].x) * qs);
+        o[2] = (__bf16)((v[2] * cs[q].y - v[3] * sn[q].y) * qs);
+        o[3] = (__bf16)((v[3] * cs[q].y + v[2] * sn[q].y) * qs);
+        if (m < p.M) *reinterpret_cast<bf16x4*>(p.qk + (size_t)m * (2 * D) + which * D + nd) = o;
+    }
+}
+
+// Whole-wave epilogue.  `slab` = wave-private LDS (32 * 32 * TN floats); m_wave / n_wave = first row / (padded) column of
+// the wave's sub-tile; n_blk = first column of the workgroup tile (uniform per workgroup, selects q/k vs v).
+// Every wave of the workgroup must call this (it contains workgroup barriers around the slab reuse).
+template <int EPI, int TM, int TN>
+F5_DEVICE void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[TM][TN], float* slab, int m_wave, int n_wave, int n_blk, int lane) {
+    constexpr int WN = TN * 32;
+    const int fr = lane & 31, fh = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < TM; i++) {
+        const int m_base = m_wave + i * 32;
+        if (EPI == EPI_QKV && n_blk >= 2 * p.D) {
+            // V block: written transposed ([feature][token]) straight from the accumulators, 4 tokens = 8 bytes per store
+#pragma unroll
+            for (int j = 0; j < TN; j++) {
+                const int nd = n_wave - 2 * p.D + j * 32 + fr;
+                const float bv = p.bias[n_wave + j * 32 + fr];
+#pragma unroll
+                for (int a4 = 0; a4 < 4; a4++) {
+                    bf16x4 pk;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) pk[e] = (__bf16)(acc[i][j][a4 * 4 + e] + bv);
+                    *reinterpret_cast<bf16x4*>(p.vt + (size_t)nd * p.ldvt + m_base + 8 * a4 + 4 * fh) = pk;
+                }
+            }
+            continue;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int g = 0; g < 16; g++) slab[((g & 3) + 8 * (g >> 2) + 4 * fh) * WN + j * 32 + fr] = acc[i][j][g];
+        __syncthreads();
+        if (EPI == EPI_GENERIC) {
+            switch (p.act) {
+                case ACT_GELU_TANH: epi_generic_rows<ACT_GELU_TANH, WN>(p, slab, m_base, n_wave, lane); break;
+                case ACT_GELU_ERF: epi_generic_rows<ACT_GELU_ERF, WN>(p, slab, m_base, n_wave, lane); break;
+                case ACT_MISH: epi_generic_rows<ACT_MISH, WN>(p, slab, m_base, n_wave, lane); break;
+                case ACT_SILU: epi_generic_rows<ACT_SILU, WN>(p, slab, m_base, n_wave, lane); break;
+                default: epi_generic_rows<ACT_NONE, WN>(p, slab, m_base, n_wave, lane); break;
+            }
+        } else {
+            epi_qk_rows<WN>(p, slab, m_base, n_wave, lane);
+        }
+    }
+}
