@@ -1,0 +1,100 @@
+"""CPU: the C-ABI library loads and exports every symbol include/f5hip.h declares (no compute without a GPU);
+the multi-GPU layer (unit sharding, broadcast of reference latents, waveform gather) on gloo, world_size 2."""
+import ctypes
+import os
+import re
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from tts_indic_server_f5_amd import _lib, build
+    path = build.build(verbose=False)
+    lib = ctypes.CDLL(path)
+    header = open(os.path.join(ROOT, "include", "f5hip.h")).read()
+    declared = set(re.findall(r"\b(f5hip_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    for name in declared:
+        getattr(lib, name)
+    lib.f5hip_abi_version.restype = ctypes.c_int
+    assert lib.f5hip_abi_version() == 1
+
+
+def test_no_cpu_fallback_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from tts_indic_server_f5_amd import _lib, synth
+    from tts_indic_server_f5_amd.model import DiTArch, F5HipModel
+    arch = dict(dim=128, depth=1, heads=2, ff_mult=2, text_dim=64, conv_layers=1, text_num_embeds=8)
+    with pytest.raises((_lib.F5HipError, RuntimeError, AssertionError)):
+        F5HipModel(DiTArch(**arch), synth.dit_state_dict(**arch), device="cuda:0")
+    with pytest.raises(_lib.F5HipError):
+        F5HipModel(DiTArch(**arch), synth.dit_state_dict(**arch), device="cpu")
+
+
+def test_product_package_never_imports_oracle():
+    pkg = os.path.join(ROOT, "tts-indic-server-f5_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip")):
+                src = open(os.path.join(dirpath, f), encoding="utf-8").read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f
+
+
+def test_shard_units_balanced_and_deterministic():
+    from tts_indic_server_f5_amd.sharding import shard_units, unit_cost
+    frames = [1404] * 64
+    sh = shard_units(frames, 8)
+    assert sorted(sum(sh, [])) == list(range(64)) and all(len(s) == 8 for s in sh)
+    ragged = [700 + 37 * ((i * 7919) % 40) for i in range(61)]
+    sh = shard_units(ragged, 8)
+    assert sorted(sum(sh, [])) == list(range(61))
+    loads = [sum(unit_cost(ragged[i]) for i in s) for s in sh]
+    assert max(loads) / (sum(loads) / 8) < 1.08
+    assert sh == shard_units(ragged, 8)
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    from tts_indic_server_f5_amd.sharding import broadcast_ref_latents, gather_waves, shard_units
+    g = torch.Generator().manual_seed(3)
+    cond = torch.randn(469, 100, generator=g) if rank == 0 else None
+    ids = torch.randint(0, 2545, (60,), generator=g) if rank == 0 else None
+    c, i = broadcast_ref_latents(cond, ids, torch.device("cpu"))
+    ok = c.shape == (469, 100) and i.shape == (60,) and i.dtype == torch.int64
+    g2 = torch.Generator().manual_seed(3)
+    ok = ok and torch.equal(c, torch.randn(469, 100, generator=g2)) and torch.equal(i, torch.randint(0, 2545, (60,), generator=g2))
+    mine = shard_units([1404, 900, 1200, 700, 1404], world)[rank]
+    wave = torch.full((1000 + 100 * rank,), float(rank))
+    got = gather_waves(wave, dst=0)
+    if rank == 0:
+        ok = ok and len(got) == world and all(got[r].numel() == 1000 + 100 * r and float(got[r][5]) == r for r in range(world))
+    else:
+        ok = ok and got is None
+    q.put((rank, bool(ok), mine))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_broadcast_and_gather_gloo_world2():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+    assert all(ok for _, ok, _ in res), res
+    assert sorted(res[0][2] + res[1][2]) == [0, 1, 2, 3, 4]
