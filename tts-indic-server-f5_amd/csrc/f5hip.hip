@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "attn.h"
+#include "attn2.h"
 #include "common.h"
 #include "elementwise.h"
 #include "gemm.h"
@@ -265,7 +266,8 @@ static int ensure_workspace(f5hip_dit* m, int rows_pad, int frames, int n_seq) {
         m->hn = a.plane2(R * D + 256); m->c1 = a.plane2(R * D + 256); m->ao = a.plane2(R * D); m->ff = a.plane2(R * F);
         m->xs = a.plane2(R * 128); m->tn = a.plane2(R * Td); m->tg = a.plane2(R * 2 * Td); m->act = a.plane2(R * (128 + Td));
         m->sinp = a.plane2(128 * 256); m->t1 = a.plane2((size_t)128 * D); m->st = a.plane2((size_t)128 * D);
-        m->qk = a.bf16(R * 2 * D); m->vt = a.bf16((size_t)D * R);
+        // qk: +256 rows because the last 256-query tile of attn2 may read (never store) past the padded rows
+        m->qk = a.bf16((R + 256) * 2 * D); m->vt = a.bf16((size_t)D * R);
         if (!pass) {
             if (hipMalloc(&m->ws.ptr, a.used()) != hipSuccess) { m->ws.ptr = nullptr; m->cap_rows = 0; return fail(-5, "hipMalloc workspace %zu bytes", a.used()); }
             if (hipMemset(m->ws.ptr, 0, a.used()) != hipSuccess) return fail(-5, "hipMemset workspace");
@@ -537,8 +539,11 @@ static int forward_step(f5hip_dit* m, int ti, int n_blocks, hipStream_t st) {
         AttnArgs at;
         at.qk = m->qk; at.vt = m->vt; at.D = D; at.ldvt = m->M_pad; at.seq_row0 = m->d_seq_row0; at.seq_len = m->d_seq_len;
         at.seq_kvlen = m->d_seq_kvlen; at.out_hi = m->ao.hi; at.out_lo = m->nsplit == 2 ? m->ao.lo : nullptr;
+        static int attn_impl = -1;
+        if (attn_impl < 0) { const char* env = getenv("F5HIP_ATTN_IMPL"); attn_impl = env ? atoi(env) : 2; }
         prof_begin(PROF_ATTN, st);
-        hipLaunchKernelGGL(attn_fwd_kernel, dim3((m->max_len + 127) / 128, c.heads, m->n_seq), dim3(256), 0, st, at);
+        if (attn_impl == 1) hipLaunchKernelGGL(attn_fwd_kernel, dim3((m->max_len + 127) / 128, c.heads, m->n_seq), dim3(256), 0, st, at);
+        else hipLaunchKernelGGL(attn2_fwd_kernel, dim3((m->max_len + 255) / 256, c.heads, m->n_seq), dim3(512), 0, st, at);
         prof_end(PROF_ATTN, st);
         CKL("attention");
         GemmArgs o = gemm_base(m->ao, D, m->wout[l], M);
