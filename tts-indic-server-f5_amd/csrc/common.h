@@ -28,18 +28,24 @@ F5_DEVICE void split_bf16x4(const float* y, bf16x4& hi, bf16x4& lo) {
     }
 }
 
+// Activations on the hardware transcendental units (v_exp_f32 / v_rcp_f32 / v_log_f32, ~1 ulp each): the libm forms
+// (tanhf, expf, log1pf) expand to 25-40 instructions per element and dominated the GEMM epilogues.
+F5_DEVICE float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+F5_DEVICE float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
 F5_DEVICE float gelu_tanh_f(float x) {
-    // torch GELU(approximate="tanh"): 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
+    // torch GELU(approximate="tanh"): 0.5 x (1 + tanh(u)), u = sqrt(2/pi) (x + 0.044715 x^3);  0.5 (1 + tanh u) = 1 / (1 + e^{-2u})
     const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-    float u = k0 * (x + k1 * x * x * x);
-    return 0.5f * x * (1.0f + tanhf(u));
+    const float u = k0 * (x + k1 * x * x * x);
+    return x * fast_rcp(1.0f + fast_exp(-2.0f * u));
 }
 F5_DEVICE float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f)); }
-F5_DEVICE float silu_f(float x) { return x / (1.0f + expf(-x)); }
+F5_DEVICE float silu_f(float x) { return x * fast_rcp(1.0f + fast_exp(-x)); }
 F5_DEVICE float mish_f(float x) {
-    // x * tanh(softplus(x)), softplus with torch's threshold 20
-    float sp = x > 20.0f ? x : log1pf(expf(x));
-    return x * tanhf(sp);
+    // x * tanh(softplus(x));  with e = e^x: tanh(log(1 + e)) = (e^2 + 2e) / (e^2 + 2e + 2);  x > 20: tanh(softplus) == 1 in fp32
+    const float e = fast_exp(fminf(x, 20.0f));
+    const float n = e * (e + 2.0f);
+    return x * n * fast_rcp(n + 2.0f);
 }
 
 F5_DEVICE float wave_sum(float v) {

@@ -108,14 +108,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
             for (int g = 0; g < 16; g++) acc[i][j][g] = 0.0f;
 
+    // ABL == 3 (diagnostics): s_memtime stamps of workgroup (0,0) wave 0 accumulated per phase into p.stamps[0..7]
+    unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_prev = 0, st_begin = 0;
+#define STAMP(IDX)                                                                                   \
+    if constexpr (ABL == 3) {                                                                        \
+        unsigned long long t_;                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                           \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                  \
+        __builtin_amdgcn_sched_barrier(0);                                                           \
+        if ((IDX) >= 0) st_acc[(IDX) < 0 ? 0 : (IDX)] += t_ - st_prev; else st_begin = t_;           \
+        st_prev = t_;                                                                                \
+    }
+    STAMP(-1);
     LOAD_TILES(0);
     STORE_TILES(0);
     __syncthreads();
+    STAMP(0);   // prologue
 
     const int fr = lane & 31, fh = lane >> 5;
     for (int kt = 0; kt < nk; kt++) {
         const bool more = kt + 1 < nk;
         if (more && ABL != 1) LOAD_TILES(kt + 1);
+        STAMP(1);   // global load issue
         const char* base = smem + (kt & 1) * STAGE;
 #pragma unroll
         for (int s = 0; s < (ABL == 2 ? 0 : 2); s++) {
@@ -141,14 +155,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[0][j], acc[i][j], 0, 0, 0);
                 }
         }
+        STAMP(2);   // LDS reads + MFMAs
         if (more && ABL != 1) STORE_TILES((kt + 1) & 1);
+        STAMP(3);   // wait for the global loads + LDS writes
         __syncthreads();
+        STAMP(4);   // barrier
     }
 #undef LOAD_TILES
 #undef STORE_TILES
 
     // ---------------------------------------------------------------- epilogue (gemm_epilogue.h)
     gemm_epilogue<EPI, TM, TN>(p, acc, reinterpret_cast<float*>(smem) + wave * 2048, m0 + wm * (TM * 32), n0 + wn * 64, n0, lane);
+    STAMP(5);   // epilogue
+    if constexpr (ABL == 3) {
+        if (p.stamps && blockIdx.x == p.stamp_bx && blockIdx.y == p.stamp_by && tid == 0) {
+            for (int i = 0; i < 6; i++) p.stamps[i] = st_acc[i];
+            p.stamps[6] = st_prev - st_begin;
+        }
+    }
+#undef STAMP
 }
 
 template <int NSPLIT, int BN, bool CONV, int EPI, int ABL = 0>

@@ -115,7 +115,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 }
         }
     }
-    __syncthreads();   // all waves done with the ring (no DMA outstanding: the last iterations waited vmcnt(0))
     gemm_epilogue<EPI, TM, TN>(p, acc, reinterpret_cast<float*>(smem) + wave * (32 * 32 * TN), m0 + wm * (TM * 32), n0 + wn * (TN * 32), n0,
                                lane);
 }

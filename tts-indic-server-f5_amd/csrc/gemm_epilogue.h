@@ -43,6 +43,9 @@ struct GemmArgs {
     __bf16* qk;              // [M_pad][2 D]
     __bf16* vt;              // [D][ldvt]
     int ldvt;
+    // diagnostics (ABL == 3 builds only)
+    unsigned long long* stamps;
+    int stamp_bx, stamp_by;
 };
 
 // one 32 x WN slice staged in `stg` (fp32, row stride WN): generic epilogue, lane owns 4 columns of 32 / RPP rows
@@ -134,11 +137,14 @@ F5_DEVICE void epi_qk_rows(const GemmArgs& p, const float* stg, int m_base, int 
 
 // Whole-wave epilogue.  `slab` = wave-private LDS (32 * 32 * TN floats); m_wave / n_wave = first row / (padded) column of
 // the wave's sub-tile; n_blk = first column of the workgroup tile (uniform per workgroup, selects q/k vs v).
-// Every wave of the workgroup must call this (it contains workgroup barriers around the slab reuse).
+// Every wave of the workgroup must call this: one workgroup barrier protects the k-loop stages the slabs alias; after it
+// the slab is wave-private, DS operations of one wave execute in order, so a wavefront-scope fence (compiler ordering
+// only, no instruction) is all that separates the transposing writes from the row reads.
 template <int EPI, int TM, int TN>
 F5_DEVICE void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[TM][TN], float* slab, int m_wave, int n_wave, int n_blk, int lane) {
     constexpr int WN = TN * 32;
     const int fr = lane & 31, fh = lane >> 5;
+    __syncthreads();
 #pragma unroll
     for (int i = 0; i < TM; i++) {
         const int m_base = m_wave + i * 32;
@@ -158,12 +164,12 @@ F5_DEVICE void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[TM][TN], float* sl
             }
             continue;
         }
-        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
 #pragma unroll
         for (int j = 0; j < TN; j++)
 #pragma unroll
             for (int g = 0; g < 16; g++) slab[((g & 3) + 8 * (g >> 2) + 4 * fh) * WN + j * 32 + fr] = acc[i][j][g];
-        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         if (EPI == EPI_GENERIC) {
             switch (p.act) {
                 case ACT_GELU_TANH: epi_generic_rows<ACT_GELU_TANH, WN>(p, slab, m_base, n_wave, lane); break;
