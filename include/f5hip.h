@@ -28,6 +28,7 @@ const char* f5hip_last_error(void);
 typedef struct f5hip_dit_config {
     int32_t dim, depth, heads, ff_mult, text_dim, conv_layers, mel_dim, text_num_embeds;
     int32_t gemm_planes; /* 2 = split-bf16 "bf16x3" GEMMs (parity mode, default), 1 = plain bf16 (fast, ~8e-3 mel RMS) */
+    int32_t arch;        /* 0 = DiT (F5-TTS, F/model/backbones/dit.py), 1 = UNetT (E2-TTS, F/model/backbones/unett.py: text_dim = mel_dim, conv_layers = 0) */
 } f5hip_dit_config;
 
 typedef struct f5hip_dit f5hip_dit;

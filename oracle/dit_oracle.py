@@ -289,3 +289,59 @@ def cfm_sample(sd, cfg: DiTConfig, cond: torch.Tensor, text: torch.Tensor, durat
     last = traj[-1] if keep_trajectory else traj
     out = torch.where(cond_mask, cond, last)
     return out, (traj if keep_trajectory else None)
+
+
+# ----------------------------------------------------------------------------
+# UNetT (E2-TTS) backbone, F/model/backbones/unett.py:96-219
+# ----------------------------------------------------------------------------
+
+@dataclass(frozen=True)
+class UNetTConfig:
+    """model.arch of F/configs/E2TTS_{Base,Small}_train.yaml:24-28 (text_dim defaults to mel_dim, no text conv)."""
+    dim: int = 1024
+    depth: int = 24
+    heads: int = 16
+    ff_mult: int = 4
+    mel_dim: int = 100
+    text_num_embeds: int = 2545
+    dim_head: int = 64
+    # DiT-compatible fields used by the shared helpers
+    text_dim: int = 100
+    conv_layers: int = 0
+
+
+E2_BASE = UNetTConfig()
+E2_SMALL = UNetTConfig(dim=768, depth=20, heads=12)
+
+
+def rms_norm(x: torch.Tensor, g: torch.Tensor) -> torch.Tensor:
+    """x-transformers 2.2.8 RMSNorm (call sites unett.py:17,135,144,161): F.normalize(x, dim=-1) * sqrt(dim) * g."""
+    return F.normalize(x, dim=-1) * (x.shape[-1] ** 0.5) * g
+
+
+def unett_forward(sd, cfg: UNetTConfig, x, cond, text, time, drop_audio_cond: bool, drop_text: bool, mask=None) -> torch.Tensor:
+    """UNetT.forward, F/model/backbones/unett.py:164-219 (skip_connect_type="concat")."""
+    b, n = x.shape[:2]
+    if time.ndim == 0:
+        time = time.repeat(b)
+    t = time_embed(sd, time)
+    te = text_embed(sd, cfg, text, n, drop_text)
+    h = input_embed(sd, x, cond, te, drop_audio_cond)
+    h = torch.cat([t.unsqueeze(1), h], dim=1)                       # time token first (unett.py:184)
+    if mask is not None:
+        mask = F.pad(mask, (1, 0), value=True)
+    rope = rotary_freqs(n + 1, cfg.dim_head)
+    skips = []
+    for i in range(cfg.depth):
+        p = f"transformer.layers.{i}."
+        if i < cfg.depth // 2:
+            skips.append(h)
+        else:
+            h = F.linear(torch.cat((h, skips.pop()), dim=-1), sd[p + "0.weight"])
+        h = attention(sd, p + "2.", cfg, rms_norm(h, sd[p + "1.g"]), mask, rope) + h
+        f = F.linear(rms_norm(h, sd[p + "3.g"]), sd[p + "4.ff.0.0.weight"], sd[p + "4.ff.0.0.bias"])
+        f = F.gelu(f, approximate="tanh")
+        h = F.linear(f, sd[p + "4.ff.2.weight"], sd[p + "4.ff.2.bias"]) + h
+    assert not skips
+    h = rms_norm(h, sd["transformer.norm_out.g"])[:, 1:, :]
+    return F.linear(h, sd["transformer.proj_out.weight"], sd["transformer.proj_out.bias"])

@@ -219,8 +219,53 @@ def main():
         print("base sample", steps, "done", flush=True)
     del net_b, cfm_b
 
+    # ---- (4c) UNetT (E2-TTS): parameter order, tiny forward (b=1, both CFG branches), tiny CFM.sample, Small forward ----
+    gen_unett_fixtures(cfm_mod, NoMel)
+
     # ---- (5) chunk_text / glue: reference's pure-python functions -----------------------
     gen_glue_fixtures()
+
+
+UTINY = dict(dim=128, depth=4, heads=2, ff_mult=4, text_num_embeds=40)
+
+
+def gen_unett_fixtures(cfm_mod, NoMel):
+    unett_mod = importlib.import_module("f5_tts.model.backbones.unett")
+
+    def build(arch):
+        sd = synth.unett_state_dict(**arch)
+        net = unett_mod.UNetT(**arch, mel_dim=100)
+        names = [n for n, _ in net.named_parameters()]
+        assert names == [k[len("transformer."):] for k in sd.keys()], "synth UNetT key order != reference named_parameters()"
+        net.load_state_dict({k[len("transformer."):]: v for k, v in sd.items()}, strict=True)
+        return net.eval()
+
+    net = build(UTINY)
+    with open(os.path.join(HERE, "unett_param_order.json"), "w") as f:
+        json.dump([n for n, _ in net.named_parameters()], f)
+    g = torch.Generator().manual_seed(31)
+    n = 45
+    x = torch.randn(1, n, 100, generator=g)
+    cond = torch.randn(1, n, 100, generator=g) * (torch.arange(n)[None, :, None] < 15)
+    text = torch.randint(0, 40, (1, 19), generator=g)
+    tm = torch.tensor(0.41)
+    outs = {}
+    with torch.no_grad():
+        outs["out_cond"] = net(x=x, cond=cond, text=text, time=tm, drop_audio_cond=False, drop_text=False)
+        outs["out_null"] = net(x=x, cond=cond, text=text, time=tm, drop_audio_cond=True, drop_text=True)
+    cfm = cfm_mod.CFM(transformer=net, mel_spec_module=NoMel(), num_channels=100, odeint_kwargs=dict(method="euler")).eval()
+    out, traj = cfm.sample(cond=cond[:, :15], text=text, duration=45, steps=8, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=9)
+    save("unett_tiny", x=x, cond=cond, text=text, time=tm, sample_out=out, sample_traj1=traj[1], **outs)
+    small = dict(dim=768, depth=20, heads=12, ff_mult=4, text_num_embeds=2545)
+    net_s = build(small)
+    g = torch.Generator().manual_seed(32)
+    n = 150
+    xs = torch.randn(1, n, 100, generator=g)
+    cs = torch.randn(1, n, 100, generator=g) * (torch.arange(n)[None, :, None] < 50)
+    ts = torch.randint(1, 2545, (1, 40), generator=g)
+    with torch.no_grad():
+        o1 = net_s(x=xs, cond=cs, text=ts, time=torch.tensor(0.5), drop_audio_cond=False, drop_text=False)
+    save("unett_small_forward", x=xs, cond=cs, text=ts, out_cond=o1)
 
 
 def gen_glue_fixtures():
@@ -288,5 +333,13 @@ if __name__ == "__main__":
     if "--glue-only" in sys.argv:
         install_leaf_shims()
         gen_glue_fixtures()
+    elif "--unett-only" in sys.argv:
+        install_leaf_shims()
+        importlib.import_module("f5_tts.model.modules")
+
+        class NoMel(torch.nn.Identity):
+            n_mel_channels = 100
+
+        gen_unett_fixtures(importlib.import_module("f5_tts.model.cfm"), NoMel)
     else:
         main()

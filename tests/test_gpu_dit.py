@@ -120,3 +120,29 @@ def test_base_sample_vs_reference_digest(golden_dir, base_model, steps):
     assert _report(f"base sample {steps} NFE (16384 sampled generated-frame elements)", got, g["sampled"]) < 1e-3
     assert abs(gen.mean().item() - float(g["mean"])) < 1e-3 and abs(gen.std().item() - float(g["std"])) < 1e-3
     assert torch.equal(out[0, :4].cpu(), g["cond_head"])
+
+
+# ---------------------------------------------------------------- UNetT (E2-TTS), F/model/backbones/unett.py
+UTINY = dict(dim=128, depth=4, heads=2, ff_mult=4, text_num_embeds=40)
+
+
+def test_unett_tiny_vs_reference_fixture(golden_dir):
+    from tts_indic_server_f5_amd.model import F5HipModel, UNetTArch
+    g = _load(golden_dir, "unett_tiny")
+    m = F5HipModel(UNetTArch(**UTINY), synth.unett_state_dict(**UTINY))
+    for tag, da, dt in (("cond", False, False), ("null", True, True)):
+        out = m.transformer_forward(g["x"], g["cond"], g["text"], float(g["time"]), da, dt)
+        assert _report("unett tiny forward " + tag, out, g["out_" + tag]) < 1e-3
+    out, _ = m.sample(g["cond"][:, :15], g["text"], 45, steps=8, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=9)
+    assert _report("unett tiny sample", out[:, 15:], g["sample_out"][:, 15:]) < 1e-3
+    assert torch.equal(out[:, :15].cpu(), g["sample_out"][:, :15])
+
+
+def test_unett_small_forward_vs_reference_fixture(golden_dir):
+    from tts_indic_server_f5_amd.model import E2TTS_SMALL, F5HipModel
+    g = _load(golden_dir, "unett_small_forward")
+    m = F5HipModel(E2TTS_SMALL, synth.unett_state_dict(dim=768, depth=20, heads=12))
+    out = m.transformer_forward(g["x"], g["cond"], g["text"], 0.5, False, False)
+    ref = g["out_cond"]
+    e = _report("unett small forward", out, ref)
+    assert e < 1e-3 * max(1.0, ref.pow(2).mean().sqrt().item())   # un-gated residual stream: output rms is > 1

@@ -141,3 +141,25 @@ def test_mask_is_key_padding_only():
     # row 1 on its own 7 frames, no mask, must equal the masked batch result
     o1 = O.attention(sd, "transformer.transformer_blocks.0.attn.", TINY_CFG, x[1:, :7], None, None)
     assert torch.allclose(o[1, :7], o1[0], atol=1e-5)
+
+
+def test_unett_oracle_vs_reference_fixture(golden_dir):
+    """UNetT (E2-TTS) restatement vs the reference's own unett.py (fixture), incl. CFM.sample through it."""
+    names = json.load(open(os.path.join(golden_dir, "unett_param_order.json")))
+    ut = dict(dim=128, depth=4, heads=2, ff_mult=4, text_num_embeds=40)
+    assert [n[len("transformer."):] for n, _, _ in synth.unett_param_specs(**ut)] == names
+    g = _load(golden_dir, "unett_tiny")
+    sd = synth.unett_state_dict(**ut)
+    cfg = O.UNetTConfig(**ut)
+    _close(O.unett_forward(sd, cfg, g["x"], g["cond"], g["text"], g["time"], False, False), g["out_cond"], atol=1e-4)
+    _close(O.unett_forward(sd, cfg, g["x"], g["cond"], g["text"], g["time"], True, True), g["out_null"], atol=1e-4)
+    out, traj = O.cfm_sample(sd, cfg, g["cond"][:, :15], g["text"], 45, steps=8, cfg_strength=2.0, sway_sampling_coef=-1.0,
+                             seed=9, forward_fn=lambda **kw: O.unett_forward(sd, cfg, **kw))
+    _close(out, g["sample_out"], atol=3e-4, rtol=1e-4)
+    _close(traj[1], g["sample_traj1"], atol=3e-4, rtol=1e-4)
+
+
+def test_rms_norm_scale():
+    x = torch.randn(3, 5, 64)
+    y = O.rms_norm(x, torch.ones(64))
+    assert torch.allclose(y.pow(2).mean(-1), torch.ones(3, 5), atol=1e-5)   # unit RMS: ||y|| = sqrt(D)

@@ -13,7 +13,7 @@ _lib = None
 
 class DitConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("dim", "depth", "heads", "ff_mult", "text_dim", "conv_layers", "mel_dim",
-                                          "text_num_embeds", "gemm_planes")]
+                                          "text_num_embeds", "gemm_planes", "arch")]
 
 
 class VocosConfig(C.Structure):

@@ -17,6 +17,7 @@ struct LnArgs {
     const float* dw_w; const float* dw_b; const int* row_seq_start; const int* row_seq_end;
     __bf16* out_hi; __bf16* out_lo; int ldo;
     float* out_f32; int ldof;
+    int rms;   // 1: x-transformers RMSNorm, y = x / max(||x||_2, 1e-12) * sqrt(D) * scale[c]  (no mean subtraction)
 };
 
 template <int NV>
@@ -52,7 +53,7 @@ __global__ __launch_bounds__(256) void ln_kernel(const LnArgs p) {
             sum += v[i].x + v[i].y + v[i].z + v[i].w;
         }
     }
-    const float mean = wave_sum(sum) / (float)p.D;
+    const float mean = p.rms ? 0.0f : wave_sum(sum) / (float)p.D;
     float sq = 0.0f;
 #pragma unroll
     for (int i = 0; i < NV; i++) {
@@ -62,7 +63,8 @@ __global__ __launch_bounds__(256) void ln_kernel(const LnArgs p) {
             sq += a * a + b * b + cc * cc + d * d;
         }
     }
-    const float rstd = rsqrtf(wave_sum(sq) / (float)p.D + p.eps);
+    const float sqt = wave_sum(sq);
+    const float rstd = p.rms ? sqrtf((float)p.D) / fmaxf(sqrtf(sqt), 1e-12f) : rsqrtf(sqt / (float)p.D + p.eps);
 #pragma unroll
     for (int i = 0; i < NV; i++) {
         const int c = (i * 64 + lane) * 4;
@@ -217,4 +219,10 @@ __global__ __launch_bounds__(128) void gather_rows_kernel(const float* src, int 
     if (f >= n_frames) return;
     const int r = frame_row[f];
     for (int c = threadIdx.x; c < C; c += 128) dst[(size_t)f * ldd + c] = src[(size_t)r * lds + c];
+}
+
+// UNetT: the time embedding is the first token of every sequence (F/model/backbones/unett.py:184)
+__global__ __launch_bounds__(256) void set_time_token_kernel(float* h, int D, const int* seq_row0, const float* temb) {
+    float* row = h + (size_t)seq_row0[blockIdx.x] * D;
+    for (int c = threadIdx.x; c < D; c += 256) row[c] = temb[c];
 }

@@ -35,16 +35,21 @@ struct f5hip_dit {
     bool finalized = false;
     // packed weights
     PackedW time1, time2, adaln, wx, wct, conv1, conv2, proj_out;
-    std::vector<PackedW> wqkv, wout, wff1, wff2;
+    std::vector<PackedW> wqkv, wout, wff1, wff2, wskip;   // wskip: UNetT skip projections (later half of the layers)
+    std::vector<float*> g_attn, g_ff;                     // UNetT RMSNorm gains
+    float *g_out = nullptr, *zeros = nullptr;
     std::vector<TextBlock> tblk;
     float *text_emb = nullptr, *text_pos = nullptr, *rope_cos = nullptr, *rope_sin = nullptr;
+    int arch = 0;     // 0 = DiT (F5-TTS), 1 = UNetT (E2-TTS): one extra row per sequence carries the time token
+    int td_pad = 0;   // text_dim rounded up to 32 (K padding of the step-invariant input-projection operand)
     int gw = 0;       // conv_pos_embed channels per group
     int n_adaln = 0;  // depth * 6 D + 2 D
     // workspace
     int cap_rows = 0, cap_frames = 0, cap_seq = 0;
     DevBuf ws;   // one arena, carved below
     float *h = nullptr, *h0 = nullptr, *ce = nullptr, *pred = nullptr, *te = nullptr, *ty = nullptr, *gx = nullptr,
-          *mod = nullptr, *xstate = nullptr;
+          *mod = nullptr, *xstate = nullptr, *temb = nullptr;
+    std::vector<Plane2> skipbuf;
     Plane2 hn, c1, ao, ff, xs, tn, tg, act, sinp, t1, st;
     __bf16 *qk = nullptr, *vt = nullptr;
     int *meta = nullptr;   // device int arena
@@ -61,9 +66,10 @@ static int ceil_to(int v, int m) { return (v + m - 1) / m * m; }
 
 f5hip_dit* f5hip_dit_create(const f5hip_dit_config* cfg) {
     if (!cfg) { set_error("null config"); return nullptr; }
-    if (cfg->dim % 128 || cfg->dim != cfg->heads * 64 || cfg->dim % 16 || cfg->text_dim % 32 || cfg->mel_dim > 128 ||
-        cfg->dim / 16 > 64 || (cfg->gemm_planes != 1 && cfg->gemm_planes != 2)) {
-        set_error("unsupported DiT geometry (need dim %% 128 == 0, dim == 64*heads, dim/16 <= 64, text_dim %% 32 == 0, mel_dim <= 128)");
+    if (cfg->dim % 128 || cfg->dim != cfg->heads * 64 || cfg->dim % 16 || cfg->text_dim % 4 || cfg->mel_dim > 128 || cfg->mel_dim % 4 ||
+        cfg->dim / 16 > 64 || (cfg->gemm_planes != 1 && cfg->gemm_planes != 2) || cfg->arch < 0 || cfg->arch > 1 ||
+        (cfg->arch == 1 && (cfg->conv_layers != 0 || cfg->depth % 2)) || (cfg->conv_layers > 0 && cfg->text_dim % 32)) {
+        set_error("unsupported backbone geometry (need dim %% 128 == 0, dim == 64*heads, dim/16 <= 64, mel_dim <= 128, text conv needs text_dim %% 32 == 0; UNetT: even depth, no text conv)");
         return nullptr;
     }
     int dev_count = 0;
@@ -74,8 +80,10 @@ f5hip_dit* f5hip_dit_create(const f5hip_dit_config* cfg) {
     f5hip_dit* m = new f5hip_dit();
     m->cfg = *cfg;
     m->nsplit = cfg->gemm_planes;
+    m->arch = cfg->arch;
+    m->td_pad = ceil_to(cfg->text_dim, 32);
     m->gw = cfg->dim / 16;
-    m->n_adaln = cfg->depth * 6 * cfg->dim + 2 * cfg->dim;
+    m->n_adaln = cfg->arch == 0 ? cfg->depth * 6 * cfg->dim + 2 * cfg->dim : 0;
     return m;
 }
 
@@ -84,7 +92,9 @@ static void free_packed(PackedW& w) { dev_free(w.hi); dev_free(w.lo); dev_free(w
 void f5hip_dit_destroy(f5hip_dit* m) {
     if (!m) return;
     for (PackedW* w : {&m->time1, &m->time2, &m->adaln, &m->wx, &m->wct, &m->conv1, &m->conv2, &m->proj_out}) free_packed(*w);
-    for (auto* v : {&m->wqkv, &m->wout, &m->wff1, &m->wff2}) for (auto& w : *v) free_packed(w);
+    for (auto* v : {&m->wqkv, &m->wout, &m->wff1, &m->wff2, &m->wskip}) for (auto& w : *v) free_packed(w);
+    for (auto* v : {&m->g_attn, &m->g_ff}) for (float* g : *v) dev_free(g);
+    dev_free(m->g_out); dev_free(m->zeros);
     for (auto& b : m->tblk) {
         for (float* p : {b.dw_w, b.dw_b, b.ln_w, b.ln_b, b.gamma, b.beta}) dev_free(p);
         free_packed(b.pw1); free_packed(b.pw2);
@@ -128,6 +138,8 @@ int f5hip_dit_finalize(f5hip_dit* m) {
         GETP(b2, T + "time_embed.time_mlp.2.bias", D);
         if (pack_linear(m->time1, w0->data(), D, 256, 256, b0->data())) return -4;
         if (pack_linear(m->time2, w2->data(), D, D, D, b2->data())) return -4;
+    }
+    if (m->arch == 0) {
         std::vector<float> wa((size_t)m->n_adaln * D), ba(m->n_adaln);
         for (int l = 0; l < c.depth; l++) {
             std::string p = T + "transformer_blocks." + std::to_string(l) + ".attn_norm.linear.";
@@ -177,16 +189,17 @@ int f5hip_dit_finalize(f5hip_dit* m) {
         const int Kin = 2 * mel + Td;
         GETP(w, T + "input_embed.proj.weight", (int64_t)D * Kin);
         GETP(b, T + "input_embed.proj.bias", D);
-        std::vector<float> wx((size_t)D * 128, 0.0f), wct((size_t)D * (128 + Td), 0.0f);
+        const int Kct = 128 + m->td_pad;
+        std::vector<float> wx((size_t)D * 128, 0.0f), wct((size_t)D * Kct, 0.0f);
         for (int n = 0; n < D; n++) {
             for (int k = 0; k < mel; k++) {
                 wx[(size_t)n * 128 + k] = (*w)[(size_t)n * Kin + k];
-                wct[(size_t)n * (128 + Td) + k] = (*w)[(size_t)n * Kin + mel + k];
+                wct[(size_t)n * Kct + k] = (*w)[(size_t)n * Kin + mel + k];
             }
-            for (int k = 0; k < Td; k++) wct[(size_t)n * (128 + Td) + 128 + k] = (*w)[(size_t)n * Kin + 2 * mel + k];
+            for (int k = 0; k < Td; k++) wct[(size_t)n * Kct + 128 + k] = (*w)[(size_t)n * Kin + 2 * mel + k];
         }
         if (pack_linear(m->wx, wx.data(), D, 128, 128, nullptr)) return -4;
-        if (pack_linear(m->wct, wct.data(), D, 128 + Td, 128 + Td, b->data())) return -4;
+        if (pack_linear(m->wct, wct.data(), D, Kct, Kct, b->data())) return -4;
     }
     // --- conv_pos_embed: grouped Conv1d(D, D, 31, groups 16) as 16 implicit GEMMs, each padded to 64 x (31 x 64) ---
     for (int which = 0; which < 2; which++) {
@@ -207,23 +220,42 @@ int f5hip_dit_finalize(f5hip_dit* m) {
     }
     // --- transformer blocks ---
     m->wqkv.resize(c.depth); m->wout.resize(c.depth); m->wff1.resize(c.depth); m->wff2.resize(c.depth);
+    if (m->arch == 1) { m->wskip.resize(c.depth); m->g_attn.assign(c.depth, nullptr); m->g_ff.assign(c.depth, nullptr); }
     for (int l = 0; l < c.depth; l++) {
-        std::string p = T + "transformer_blocks." + std::to_string(l) + ".";
+        // DiT: transformer_blocks.{l}.attn.* / .ff.*  (F/model/modules.py:542-556);  UNetT: layers.{l}.{0 skip_proj, 1 attn_norm, 2 attn, 3 ff_norm, 4 ff}
+        const std::string p = T + (m->arch == 0 ? "transformer_blocks." : "layers.") + std::to_string(l) + ".";
+        const std::string pa = p + (m->arch == 0 ? "attn." : "2."), pf = p + (m->arch == 0 ? "ff." : "4.");
         std::vector<float> wq((size_t)3 * D * D), bq(3 * D);
         const char* nm[3] = {"to_q", "to_k", "to_v"};
         for (int i = 0; i < 3; i++) {
-            GETP(w, p + "attn." + nm[i] + ".weight", (int64_t)D * D);
-            GETP(b, p + "attn." + nm[i] + ".bias", D);
+            GETP(w, pa + nm[i] + ".weight", (int64_t)D * D);
+            GETP(b, pa + nm[i] + ".bias", D);
             memcpy(&wq[(size_t)i * D * D], w->data(), sizeof(float) * D * D);
             memcpy(&bq[(size_t)i * D], b->data(), sizeof(float) * D);
         }
         if (pack_linear(m->wqkv[l], wq.data(), 3 * D, D, D, bq.data())) return -4;
-        GETP(wo, p + "attn.to_out.0.weight", (int64_t)D * D); GETP(bo, p + "attn.to_out.0.bias", D);
+        GETP(wo, pa + "to_out.0.weight", (int64_t)D * D); GETP(bo, pa + "to_out.0.bias", D);
         if (pack_linear(m->wout[l], wo->data(), D, D, D, bo->data())) return -4;
-        GETP(w1, p + "ff.ff.0.0.weight", (int64_t)F * D); GETP(b1, p + "ff.ff.0.0.bias", F);
+        GETP(w1, pf + "ff.0.0.weight", (int64_t)F * D); GETP(b1, pf + "ff.0.0.bias", F);
         if (pack_linear(m->wff1[l], w1->data(), F, D, D, b1->data())) return -4;
-        GETP(w2, p + "ff.ff.2.weight", (int64_t)D * F); GETP(b2, p + "ff.ff.2.bias", D);
+        GETP(w2, pf + "ff.2.weight", (int64_t)D * F); GETP(b2, pf + "ff.2.bias", D);
         if (pack_linear(m->wff2[l], w2->data(), D, F, F, b2->data())) return -4;
+        if (m->arch == 1) {
+            GETP(ga, p + "1.g", D); GETP(gf, p + "3.g", D);
+            if (upload_f32(&m->g_attn[l], ga->data(), D) || upload_f32(&m->g_ff[l], gf->data(), D)) return -4;
+            if (l >= c.depth / 2) {
+                GETP(ws, p + "0.weight", (int64_t)D * 2 * D);
+                if (pack_linear(m->wskip[l], ws->data(), D, 2 * D, 2 * D, nullptr)) return -4;
+            }
+        }
+    }
+    if (m->arch == 1) {
+        GETP(go, T + "norm_out.g", D);
+        if (upload_f32(&m->g_out, go->data(), D)) return -4;
+    }
+    {
+        std::vector<float> z(std::max(D, 4096), 0.0f);
+        if (upload_f32(&m->zeros, z.data(), z.size())) return -4;
     }
     {
         GETP(w, T + "proj_out.weight", (int64_t)mel * D); GETP(b, T + "proj_out.bias", mel);
@@ -262,10 +294,12 @@ static int ensure_workspace(f5hip_dit* m, int rows_pad, int frames, int n_seq) {
         a.reset(pass ? (char*)m->ws.ptr : nullptr);
         m->h = a.f32(R * D); m->h0 = a.f32(R * D); m->ce = a.f32(R * D); m->pred = a.f32(R * 128);
         m->te = a.f32(R * Td); m->ty = a.f32(R * 2 * Td); m->gx = a.f32(S * 2 * Td);
-        m->mod = a.f32((size_t)128 * m->n_adaln); m->xstate = a.f32(U * c.mel_dim);
+        m->mod = a.f32((size_t)128 * m->n_adaln + 64); m->xstate = a.f32(U * c.mel_dim); m->temb = a.f32((size_t)128 * D);
         m->hn = a.plane2(R * D + 256); m->c1 = a.plane2(R * D + 256); m->ao = a.plane2(R * D); m->ff = a.plane2(R * F);
-        m->xs = a.plane2(R * 128); m->tn = a.plane2(R * Td); m->tg = a.plane2(R * 2 * Td); m->act = a.plane2(R * (128 + Td));
+        m->xs = a.plane2(R * 128); m->tn = a.plane2(R * Td); m->tg = a.plane2(R * 2 * Td); m->act = a.plane2(R * (128 + m->td_pad));
         m->sinp = a.plane2(128 * 256); m->t1 = a.plane2((size_t)128 * D); m->st = a.plane2((size_t)128 * D);
+        m->skipbuf.resize(m->arch == 1 ? c.depth / 2 : 0);
+        for (auto& sb : m->skipbuf) sb = a.plane2(R * D);
         // qk: +256 rows because the last 256-query tile of attn2 may read (never store) past the padded rows
         m->qk = a.bf16((R + 256) * 2 * D); m->vt = a.bf16((size_t)D * R);
         if (!pass) {
@@ -283,31 +317,37 @@ static int ensure_workspace(f5hip_dit* m, int rows_pad, int frames, int n_seq) {
     return 0;
 }
 
-struct SeqDesc { int len, kvlen, frame0 /* first frame in caller's packed arrays */, text_row, drop_audio, drop_text; };
+struct SeqDesc { int len, kvlen, frame0 /* first frame in caller's packed arrays */, text_row, drop_audio, drop_text, branch /* 0 cond, 1 uncond */; };
 
 // Lays the sequences out (each padded to a multiple of 128 rows), builds the per-row metadata and uploads it.
+// UNetT: row 0 of every sequence is the time token (F/model/backbones/unett.py:184); frames follow at rows 1..len.
 static int setup_sequences(f5hip_dit* m, const std::vector<SeqDesc>& seqs, int n_frames, const int32_t* text, int nt_max,
-                           const uint8_t* frame_is_cond, const std::vector<int>& urow_c, const std::vector<int>& urow_u,
-                           hipStream_t st) {
+                           const uint8_t* frame_is_cond, hipStream_t st) {
+    const int extra = m->arch == 1 ? 1 : 0;
     int rows = 0;
-    for (auto& s : seqs) rows += ceil_to(s.len, 128);
+    for (auto& s : seqs) rows += ceil_to(s.len + extra, 128);
     if (ensure_workspace(m, rows, n_frames, (int)seqs.size())) return -5;
     const int R = rows, S = (int)seqs.size(), U = n_frames;
     std::vector<int> hbuf((size_t)R * 8 + S * 3 + U * 3, 0);
     int* row_pos = &hbuf[0]; int* row_start = row_pos + R; int* row_end = row_start + R; int* row_seq = row_end + R;
     int* row_token = row_seq + R; int* row_frame = row_token + R; int* row_condframe = row_frame + R; int* row_keep = row_condframe + R;
     int* seq_row0 = row_keep + R; int* seq_len = seq_row0 + S; int* seq_kvlen = seq_len + S;
-    int* d_urow_c = seq_kvlen + S; int* d_urow_u = d_urow_c + U; int* fic = d_urow_u + U;
+    int* urow_c = seq_kvlen + S; int* urow_u = urow_c + U; int* fic = urow_u + U;
     int r0 = 0;
     m->any_masked = false;
     for (int r = 0; r < R; r++) { row_seq[r] = -1; row_token[r] = -1; row_frame[r] = -1; row_condframe[r] = -1; }
+    for (int u = 0; u < U; u++) { urow_c[u] = -1; urow_u[u] = -1; fic[u] = frame_is_cond ? frame_is_cond[u] : 0; }
+    m->max_len = 0;
     for (int s = 0; s < S; s++) {
         const SeqDesc& q = seqs[s];
-        seq_row0[s] = r0; seq_len[s] = q.len; seq_kvlen[s] = q.kvlen;
+        seq_row0[s] = r0; seq_len[s] = q.len + extra; seq_kvlen[s] = q.kvlen + extra;
+        m->max_len = std::max(m->max_len, q.len + extra);
         if (q.kvlen < q.len) m->any_masked = true;
+        if (extra) { row_pos[r0] = 0; row_seq[r0] = s; row_keep[r0] = 1; }   // time token: start = end = 0 keeps it out of the convs
         for (int i = 0; i < q.len; i++) {
-            const int r = r0 + i;
-            row_pos[r] = i; row_start[r] = r0; row_end[r] = r0 + q.len; row_seq[r] = s;
+            const int r = r0 + extra + i;
+            row_pos[r] = i + extra;                                   // rotary position (time token = 0)
+            row_start[r] = r0 + extra; row_end[r] = r0 + extra + q.len; row_seq[r] = s;
             int tok = 0;
             if (!q.drop_text && i < nt_max) tok = text[(size_t)q.text_row * nt_max + i] + 1;   // -1 pad -> filler 0
             row_token[r] = tok;
@@ -315,13 +355,9 @@ static int setup_sequences(f5hip_dit* m, const std::vector<SeqDesc>& seqs, int n
             const bool is_c = frame_is_cond ? frame_is_cond[q.frame0 + i] != 0 : true;
             row_condframe[r] = (!q.drop_audio && is_c) ? q.frame0 + i : -1;
             row_keep[r] = i < q.kvlen ? 1 : 0;
+            (q.branch ? urow_u : urow_c)[q.frame0 + i] = r;
         }
-        r0 += ceil_to(q.len, 128);
-    }
-    for (int u = 0; u < U; u++) {
-        d_urow_c[u] = u < (int)urow_c.size() ? urow_c[u] : -1;
-        d_urow_u[u] = u < (int)urow_u.size() ? urow_u[u] : -1;
-        fic[u] = frame_is_cond ? frame_is_cond[u] : 0;
+        r0 += ceil_to(q.len + extra, 128);
     }
     if (hipMemcpyAsync(m->meta, hbuf.data(), sizeof(int) * hbuf.size(), hipMemcpyHostToDevice, st) != hipSuccess)
         return fail(-6, "metadata upload");
@@ -333,8 +369,6 @@ static int setup_sequences(f5hip_dit* m, const std::vector<SeqDesc>& seqs, int n
     m->d_seq_row0 = d; m->d_seq_len = d + S; m->d_seq_kvlen = d + 2 * S; d += 3 * S;
     m->d_urow_c = d; m->d_urow_u = d + U; m->d_frame_is_cond = d + 2 * U;
     m->M = R; m->M_pad = R; m->n_seq = S; m->n_frames = U;
-    m->max_len = 0;
-    for (auto& q : seqs) m->max_len = std::max(m->max_len, q.len);
     return 0;
 }
 
@@ -425,7 +459,7 @@ static int run_ln(const LnArgs& a, hipStream_t st) {
 // -------------------------------------------------------------------------------------------------
 static int precompute_text_and_ce(f5hip_dit* m, const float* cond_dev, hipStream_t st) {
     const f5hip_dit_config& c = m->cfg;
-    const int D = c.dim, Td = c.text_dim, M = m->M, Kct = 128 + Td;
+    const int D = c.dim, Td = c.text_dim, M = m->M, Kct = 128 + m->td_pad;
     prof_begin(PROF_OTHER, st);
     hipLaunchKernelGGL(text_gather_kernel, dim3(M), dim3(256), 0, st, m->text_emb, m->text_pos, Td, M, m->d_row_token,
                        m->d_row_pos, c.conv_layers > 0 ? 1 : 0, m->te, Td);
@@ -495,12 +529,92 @@ static int precompute_time(f5hip_dit* m, const float* t_host, int n_t, hipStream
     g1.act = ACT_SILU; g1.out_hi = m->t1.hi; g1.out_lo = m->t1.lo; g1.ldob = D;
     int r = run_gemm(m, g1, m->time1, EPI_GENERIC, false, 128, st, 128);
     GemmArgs g2 = gemm_base(m->t1, D, m->time2, n_t);
+    if (m->arch == 1) {
+        g2.out_f32 = m->temb; g2.ldo = D;   // UNetT: the raw time embedding is prepended as a token (unett.py:184)
+        if (!r) r = run_gemm(m, g2, m->time2, EPI_GENERIC, false, 128, st, 128);
+        return r;
+    }
     g2.act = ACT_SILU; g2.out_hi = m->st.hi; g2.out_lo = m->st.lo; g2.ldob = D;   // silu(t_emb): the only form AdaLN consumes
     if (!r) r = run_gemm(m, g2, m->time2, EPI_GENERIC, false, 128, st, 128);
     GemmArgs g3 = gemm_base(m->st, D, m->adaln, n_t);
     g3.out_f32 = m->mod; g3.ldo = m->n_adaln;
     if (!r) r = run_gemm(m, g3, m->adaln, EPI_GENERIC, false, 128, st, 128);
     return r;
+}
+
+static int launch_attention(f5hip_dit* m, hipStream_t st) {
+    const f5hip_dit_config& c = m->cfg;
+    AttnArgs at;
+    at.qk = m->qk; at.vt = m->vt; at.D = c.dim; at.ldvt = m->M_pad; at.seq_row0 = m->d_seq_row0; at.seq_len = m->d_seq_len;
+    at.seq_kvlen = m->d_seq_kvlen; at.out_hi = m->ao.hi; at.out_lo = m->nsplit == 2 ? m->ao.lo : nullptr;
+    static int attn_impl = -1;
+    if (attn_impl < 0) { const char* env = getenv("F5HIP_ATTN_IMPL"); attn_impl = env ? atoi(env) : 2; }
+    prof_begin(PROF_ATTN, st);
+    if (attn_impl == 1) hipLaunchKernelGGL(attn_fwd_kernel, dim3((m->max_len + 127) / 128, c.heads, m->n_seq), dim3(256), 0, st, at);
+    else hipLaunchKernelGGL(attn2_fwd_kernel, dim3((m->max_len + 255) / 256, c.heads, m->n_seq), dim3(512), 0, st, at);
+    prof_end(PROF_ATTN, st);
+    CKL("attention");
+    return 0;
+}
+
+// UNetT (E2-TTS) layers, F/model/backbones/unett.py:184-219: time token at row 0 of every sequence, pre-norm blocks
+//   x = attn(RMSNorm(x)) + x;  x = ff(RMSNorm(x)) + x,  U-skips: layer l >= depth/2 first does x = W_skip [x || skip(depth-1-l)].
+static int forward_unett_layers(f5hip_dit* m, int ti, int n_blocks, hipStream_t st) {
+    const f5hip_dit_config& c = m->cfg;
+    const int D = c.dim, F = c.ff_mult * D, M = m->M;
+    prof_begin(PROF_OTHER, st);
+    hipLaunchKernelGGL(set_time_token_kernel, dim3(m->n_seq), dim3(256), 0, st, m->h, D, m->d_seq_row0, m->temb + (size_t)ti * D);
+    prof_end(PROF_OTHER, st);
+    CKL("set_time_token");
+    const int nb = n_blocks < 0 ? c.depth : n_blocks;
+    LnArgs ln; memset(&ln, 0, sizeof(ln));
+    ln.x = m->h; ln.ldx = D; ln.M = M; ln.D = D; ln.shift = m->zeros; ln.gain_off = 0.0f; ln.eps = 0.0f; ln.rms = 1;
+    ln.out_hi = m->hn.hi; ln.out_lo = m->hn.lo; ln.ldo = D;
+    for (int l = 0; l < nb; l++) {
+        if (l < c.depth / 2) {
+            prof_begin(PROF_OTHER, st);
+            hipLaunchKernelGGL(split_rows_kernel, dim3(M), dim3(256), 0, st, m->h, D, D, M, (const int*)nullptr, m->skipbuf[l].hi, m->skipbuf[l].lo, D, 0);
+            prof_end(PROF_OTHER, st);
+            CKL("skip save");
+        } else {
+            const Plane2& sk = m->skipbuf[c.depth - 1 - l];
+            prof_begin(PROF_OTHER, st);
+            hipLaunchKernelGGL(split_rows_kernel, dim3(M), dim3(256), 0, st, m->h, D, D, M, (const int*)nullptr, m->ff.hi, m->ff.lo, 2 * D, 0);
+            CKL("skip concat x");
+            if (hipMemcpy2DAsync(m->ff.hi + D, (size_t)2 * D * 2, sk.hi, (size_t)D * 2, (size_t)D * 2, M, hipMemcpyDeviceToDevice, st) != hipSuccess ||
+                hipMemcpy2DAsync(m->ff.lo + D, (size_t)2 * D * 2, sk.lo, (size_t)D * 2, (size_t)D * 2, M, hipMemcpyDeviceToDevice, st) != hipSuccess)
+                return fail(-6, "skip concat copy");
+            prof_end(PROF_OTHER, st);
+            GemmArgs sp = gemm_base(m->ff, 2 * D, m->wskip[l], M);
+            sp.bias = nullptr; sp.out_f32 = m->h; sp.ldo = D;
+            CK(run_gemm(m, sp, m->wskip[l], EPI_GENERIC, false, 64, st));
+        }
+        ln.scale = m->g_attn[l];
+        CK(run_ln(ln, st));
+        GemmArgs q = gemm_base(m->hn, D, m->wqkv[l], M);
+        q.D = D; q.row_pos = m->d_row_pos; q.rope_cos = m->rope_cos; q.rope_sin = m->rope_sin; q.qk = m->qk; q.vt = m->vt; q.ldvt = m->M_pad;
+        CK(run_gemm(m, q, m->wqkv[l], EPI_QKV, false, 128, st));
+        CK(launch_attention(m, st));
+        GemmArgs o = gemm_base(m->ao, D, m->wout[l], M);
+        o.res = m->h; o.ldres = D; o.out_f32 = m->h; o.ldo = D;
+        o.row_keep = m->any_masked ? m->d_row_keep : nullptr;
+        CK(run_gemm(m, o, m->wout[l], EPI_GENERIC, false, 64, st));
+        ln.scale = m->g_ff[l];
+        CK(run_ln(ln, st));
+        GemmArgs f1 = gemm_base(m->hn, D, m->wff1[l], M);
+        f1.act = ACT_GELU_TANH; f1.out_hi = m->ff.hi; f1.out_lo = m->ff.lo; f1.ldob = F;
+        CK(run_gemm(m, f1, m->wff1[l], EPI_GENERIC, false, 128, st));
+        GemmArgs f2 = gemm_base(m->ff, F, m->wff2[l], M);
+        f2.res = m->h; f2.ldres = D; f2.out_f32 = m->h; f2.ldo = D;
+        CK(run_gemm(m, f2, m->wff2[l], EPI_GENERIC, false, 64, st));
+    }
+    if (n_blocks >= 0) return 0;
+    ln.scale = m->g_out;
+    CK(run_ln(ln, st));
+    GemmArgs po = gemm_base(m->hn, D, m->proj_out, M);
+    po.out_f32 = m->pred; po.ldo = 128;
+    CK(run_gemm(m, po, m->proj_out, EPI_GENERIC, false, 128, st));
+    return 0;
 }
 
 // One DiT evaluation at time index ti for all laid-out sequences.  xs (split bf16 of x) must be current.
@@ -527,6 +641,7 @@ static int forward_step(f5hip_dit* m, int ti, int n_blocks, hipStream_t st) {
     CK(run_gemm(m, c2, m->conv2, EPI_GENERIC, true, 64, st));
 
     const int nb = n_blocks < 0 ? c.depth : n_blocks;
+    if (m->arch == 1) return forward_unett_layers(m, ti, n_blocks, st);
     for (int l = 0; l < nb; l++) {
         const float* ml = mod + (size_t)l * 6 * D;   // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
         LnArgs ln; memset(&ln, 0, sizeof(ln));
@@ -536,16 +651,7 @@ static int forward_step(f5hip_dit* m, int ti, int n_blocks, hipStream_t st) {
         GemmArgs q = gemm_base(m->hn, D, m->wqkv[l], M);
         q.D = D; q.row_pos = m->d_row_pos; q.rope_cos = m->rope_cos; q.rope_sin = m->rope_sin; q.qk = m->qk; q.vt = m->vt; q.ldvt = m->M_pad;
         CK(run_gemm(m, q, m->wqkv[l], EPI_QKV, false, 128, st));
-        AttnArgs at;
-        at.qk = m->qk; at.vt = m->vt; at.D = D; at.ldvt = m->M_pad; at.seq_row0 = m->d_seq_row0; at.seq_len = m->d_seq_len;
-        at.seq_kvlen = m->d_seq_kvlen; at.out_hi = m->ao.hi; at.out_lo = m->nsplit == 2 ? m->ao.lo : nullptr;
-        static int attn_impl = -1;
-        if (attn_impl < 0) { const char* env = getenv("F5HIP_ATTN_IMPL"); attn_impl = env ? atoi(env) : 2; }
-        prof_begin(PROF_ATTN, st);
-        if (attn_impl == 1) hipLaunchKernelGGL(attn_fwd_kernel, dim3((m->max_len + 127) / 128, c.heads, m->n_seq), dim3(256), 0, st, at);
-        else hipLaunchKernelGGL(attn2_fwd_kernel, dim3((m->max_len + 255) / 256, c.heads, m->n_seq), dim3(512), 0, st, at);
-        prof_end(PROF_ATTN, st);
-        CKL("attention");
+        CK(launch_attention(m, st));
         GemmArgs o = gemm_base(m->ao, D, m->wout[l], M);
         o.mul = ml + 2 * D; o.res = m->h; o.ldres = D; o.out_f32 = m->h; o.ldo = D;
         o.row_keep = m->any_masked ? m->d_row_keep : nullptr;
@@ -581,19 +687,16 @@ int f5hip_dit_forward(f5hip_dit* m, int32_t n_seq, const int32_t* seq_len, const
     if (n_seq <= 0 || !seq_len || !x_dev || !cond_dev || !text) return fail(-1, "dit_forward: bad argument");
     hipStream_t st = (hipStream_t)stream;
     std::vector<SeqDesc> seqs(n_seq);
-    std::vector<int> frame_row;
-    int f0 = 0, r0 = 0;
+    int f0 = 0;
     m->h_seq_len.assign(n_seq, 0);
     for (int i = 0; i < n_seq; i++) {
         if (seq_len[i] <= 0 || seq_len[i] > 4096) return fail(-1, "seq_len[%d] = %d out of range", i, seq_len[i]);
-        seqs[i] = {seq_len[i], kv_len ? kv_len[i] : seq_len[i], f0, i, drop_audio_cond ? drop_audio_cond[i] : 0, drop_text ? drop_text[i] : 0};
+        seqs[i] = {seq_len[i], kv_len ? kv_len[i] : seq_len[i], f0, i, drop_audio_cond ? drop_audio_cond[i] : 0, drop_text ? drop_text[i] : 0, 0};
         if (seqs[i].kvlen <= 0 || seqs[i].kvlen > seqs[i].len) return fail(-1, "kv_len[%d] out of range", i);
         m->h_seq_len[i] = seq_len[i];
-        for (int k = 0; k < seq_len[i]; k++) frame_row.push_back(r0 + k);
         f0 += seq_len[i];
-        r0 += ceil_to(seq_len[i], 128);
     }
-    CK(setup_sequences(m, seqs, f0, text, nt_max, nullptr, frame_row, {}, st));
+    CK(setup_sequences(m, seqs, f0, text, nt_max, nullptr, st));
     const int M = m->M, mel = m->cfg.mel_dim, D = m->cfg.dim;
     hipLaunchKernelGGL(split_rows_kernel, dim3(M), dim3(256), 0, st, x_dev, mel, mel, M, m->d_row_frame, m->xs.hi, m->xs.lo, 128, 0);
     CKL("split x");
@@ -635,24 +738,19 @@ int f5hip_cfm_sample(f5hip_dit* m, int32_t n_utt, const int32_t* dur, const floa
     const bool use_cfg = !(cfg_strength < 1e-5f);
     const int mel = m->cfg.mel_dim;
     std::vector<SeqDesc> seqs;
-    std::vector<int> urow_c, urow_u;
-    int f0 = 0, r0 = 0;
+    int f0 = 0;
     m->h_seq_len.clear();
     for (int u = 0; u < n_utt; u++) {
         if (dur[u] <= 0 || dur[u] > 4096) return fail(-1, "dur[%d] = %d out of range", u, dur[u]);
-        seqs.push_back({dur[u], dur[u], f0, u, 0, 0});
+        seqs.push_back({dur[u], dur[u], f0, u, 0, 0, 0});
         m->h_seq_len.push_back(dur[u]);
-        const int rc = r0; r0 += ceil_to(dur[u], 128);
-        int ru = -1;
         if (use_cfg) {
-            seqs.push_back({dur[u], dur[u], f0, u, 1, 1});
+            seqs.push_back({dur[u], dur[u], f0, u, 1, 1, 1});
             m->h_seq_len.push_back(dur[u]);
-            ru = r0; r0 += ceil_to(dur[u], 128);
         }
-        for (int i = 0; i < dur[u]; i++) { urow_c.push_back(rc + i); urow_u.push_back(ru < 0 ? -1 : ru + i); }
         f0 += dur[u];
     }
-    CK(setup_sequences(m, seqs, f0, text, nt_max, cond_mask, urow_c, urow_u, st));
+    CK(setup_sequences(m, seqs, f0, text, nt_max, cond_mask, st));
     const int M = m->M;
     if (hipMemcpyAsync(m->xstate, y0_dev, sizeof(float) * (size_t)f0 * mel, hipMemcpyDeviceToDevice, st) != hipSuccess)
         return fail(-6, "y0 copy");

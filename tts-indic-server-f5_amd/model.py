@@ -34,6 +34,29 @@ F5TTS_BASE = DiTArch()
 F5TTS_SMALL = DiTArch(dim=768, depth=18, heads=12)
 
 
+@dataclass(frozen=True)
+class UNetTArch:
+    """model.arch of F/configs/E2TTS_*_train.yaml:24-28: flat-UNet transformer, text_dim = mel_dim, no text conv."""
+    dim: int = 1024
+    depth: int = 24
+    heads: int = 16
+    ff_mult: int = 4
+    mel_dim: int = 100
+    text_num_embeds: int = 2545
+
+    @property
+    def text_dim(self):
+        return self.mel_dim
+
+    @property
+    def conv_layers(self):
+        return 0
+
+
+E2TTS_BASE = UNetTArch()
+E2TTS_SMALL = UNetTArch(dim=768, depth=20, heads=12)
+
+
 def _i32(a):
     return np.ascontiguousarray(np.asarray(a, dtype=np.int32))
 
@@ -45,7 +68,7 @@ def _ptr(t):
 
 
 class F5HipModel:
-    def __init__(self, arch: DiTArch, state_dict: dict, vocab_char_map: dict | None = None, gemm_planes: int = 2,
+    def __init__(self, arch: DiTArch | UNetTArch, state_dict: dict, vocab_char_map: dict | None = None, gemm_planes: int = 2,
                  device: str | torch.device = "cuda:0", mel_spec_type: str = "vocos"):
         self.arch = arch
         self.device = torch.device(device)
@@ -58,7 +81,7 @@ class F5HipModel:
             raise _lib.F5HipError("F5HipModel needs a HIP device (no CPU fallback)")
         torch.cuda.set_device(self.device)
         cfg = _lib.DitConfig(arch.dim, arch.depth, arch.heads, arch.ff_mult, arch.text_dim, arch.conv_layers,
-                             arch.mel_dim, arch.text_num_embeds, gemm_planes)
+                             arch.mel_dim, arch.text_num_embeds, gemm_planes, 1 if isinstance(arch, UNetTArch) else 0)
         self._h = self._lib.f5hip_dit_create(C.byref(cfg))
         if not self._h:
             raise _lib.F5HipError("f5hip_dit_create: " + self._lib.f5hip_last_error().decode())

@@ -57,6 +57,36 @@ def dit_param_specs(dim=1024, depth=22, heads=16, ff_mult=2, text_dim=512, conv_
     return s
 
 
+def unett_param_specs(dim=1024, depth=24, heads=16, ff_mult=4, mel_dim=100, text_num_embeds=2545, dim_head=64):
+    """Ordered (name, shape, kind) list mirroring UNetT.__init__ (F/model/backbones/unett.py:113-162)."""
+    inner = heads * dim_head
+    text_dim = mel_dim
+    s = []
+    p = "transformer.time_embed.time_mlp."
+    s += [(p + "0.weight", (dim, 256), "linear"), (p + "0.bias", (dim,), "bias"),
+          (p + "2.weight", (dim, dim), "linear"), (p + "2.bias", (dim,), "bias")]
+    s += [("transformer.text_embed.text_embed.weight", (text_num_embeds + 1, text_dim), "embed")]
+    p = "transformer.input_embed."
+    s += [(p + "proj.weight", (dim, mel_dim * 2 + text_dim), "linear"), (p + "proj.bias", (dim,), "bias")]
+    for j in (0, 2):
+        s += [(f"{p}conv_pos_embed.conv1d.{j}.weight", (dim, dim // 16, 31), "conv"),
+              (f"{p}conv_pos_embed.conv1d.{j}.bias", (dim,), "bias")]
+    for i in range(depth):
+        q = f"transformer.layers.{i}."
+        if i >= depth // 2:
+            s += [(q + "0.weight", (dim, dim * 2), "linear")]
+        s += [(q + "1.g", (dim,), "gain")]
+        for nm in ("to_q", "to_k", "to_v"):
+            s += [(f"{q}2.{nm}.weight", (inner, dim), "linear"), (f"{q}2.{nm}.bias", (inner,), "bias")]
+        s += [(q + "2.to_out.0.weight", (dim, inner), "linear"), (q + "2.to_out.0.bias", (dim,), "bias")]
+        s += [(q + "3.g", (dim,), "gain")]
+        s += [(q + "4.ff.0.0.weight", (dim * ff_mult, dim), "linear"), (q + "4.ff.0.0.bias", (dim * ff_mult,), "bias"),
+              (q + "4.ff.2.weight", (dim, dim * ff_mult), "linear"), (q + "4.ff.2.bias", (dim,), "bias")]
+    s += [("transformer.norm_out.g", (dim,), "gain"),
+          ("transformer.proj_out.weight", (mel_dim, dim), "linear"), ("transformer.proj_out.bias", (mel_dim,), "bias")]
+    return s
+
+
 def vocos_param_specs(in_ch=100, dim=512, inter=1536, layers=8, n_fft=1024):
     """Ordered (name, shape, kind) list for vocos 0.1.0 `charactr/vocos-mel-24khz`."""
     s = [("backbone.embed.weight", (dim, in_ch, 7), "conv"), ("backbone.embed.bias", (dim,), "bias"),
@@ -104,6 +134,10 @@ def make_state_dict(specs, seed):
 
 def dit_state_dict(seed=SEED_DIT, **arch):
     return make_state_dict(dit_param_specs(**arch), seed)
+
+
+def unett_state_dict(seed=SEED_DIT, **arch):
+    return make_state_dict(unett_param_specs(**arch), seed)
 
 
 def vocos_state_dict(seed=SEED_VOCOS, **arch):
