@@ -102,12 +102,44 @@ int f5hip_vocos_finalize(f5hip_vocos* v);
 int f5hip_vocos_decode(f5hip_vocos* v, int32_t batch, int32_t frames, const float* mel_dev, float* wave_dev,
                        void* stream);
 
+/* ---------------------------------------------------------------- BigVGAN vocoder --------------------- */
+
+/* BigVGAN v2 generator hyper-parameters (config.json of nvidia/bigvgan_v2_24khz_100band_256x: F/infer/utils_infer.py:122-126).
+ * Supported family: upsample_kernel_sizes[i] == 2 * upsample_rates[i] (even), resblock "1" with three kernel sizes x three
+ * dilations, snakebeta with log-scale parameters, no tanh / no bias at the final conv. */
+typedef struct f5hip_bigvgan_config {
+    int32_t num_mels, num_upsamples;
+    int32_t upsample_rates[8], upsample_kernel_sizes[8];
+    int32_t upsample_initial_channel;
+    int32_t resblock_kernel_sizes[3];
+    int32_t resblock_dilations[9];   /* [kernel index][dilation index] */
+    int32_t gemm_planes;
+} f5hip_bigvgan_config;
+typedef struct f5hip_bigvgan f5hip_bigvgan;
+
+/* Replaces bigvgan.BigVGAN.from_pretrained + remove_weight_norm (F/infer/utils_infer.py:116-129); names are the generator's
+ * state_dict keys after remove_weight_norm ("conv_pre.weight", "ups.0.0.weight", "resblocks.0.convs1.0.weight",
+ * "resblocks.0.activations.0.act.alpha", ..., "activation_post.act.beta", "conv_post.weight"). */
+f5hip_bigvgan* f5hip_bigvgan_create(const f5hip_bigvgan_config* cfg);
+void f5hip_bigvgan_destroy(f5hip_bigvgan* v);
+int f5hip_bigvgan_load_param(f5hip_bigvgan* v, const char* name, const float* data, int64_t numel);
+int f5hip_bigvgan_finalize(f5hip_bigvgan* v);
+/* Replaces vocoder(mel) (F/infer/utils_infer.py:474): mel_dev fp32 [batch][num_mels][frames] ->
+ * wave_dev fp32 [batch][frames * prod(upsample_rates)] (the reference's [batch, 1, n] squeezed), clamped to [-1, 1]. */
+int f5hip_bigvgan_forward(f5hip_bigvgan* v, int32_t batch, int32_t frames, const float* mel_dev, float* wave_dev, void* stream);
+
 /* ---------------------------------------------------------------- mel front-end ------------------------ */
 
 /* Replaces MelSpec.forward with mel_spec_type="vocos" (F/model/modules.py:75-101,130-143): wave_dev fp32
  * [batch][n_samples] -> mel_dev fp32 [batch][n_mels][1 + n_samples / hop] (log of clamp(mel, 1e-5)). */
 int f5hip_mel_spectrogram(int32_t batch, int32_t n_samples, const float* wave_dev, float* mel_dev, int32_t n_fft,
                           int32_t hop_length, int32_t n_mels, int32_t sample_rate, void* stream);
+
+/* Replaces MelSpec.forward with mel_spec_type="bigvgan" (get_bigvgan_mel_spectrogram, F/model/modules.py:30-72): reflect pad
+ * (n_fft - hop) / 2, STFT center=False, sqrt(re^2 + im^2 + 1e-9), librosa Slaney mel filterbank (fmax = sr / 2),
+ * log(clamp(., 1e-5)): wave_dev fp32 [batch][n_samples] -> mel_dev fp32 [batch][n_mels][1 + (n_samples - hop) / hop]. */
+int f5hip_mel_spectrogram_bigvgan(int32_t batch, int32_t n_samples, const float* wave_dev, float* mel_dev, int32_t n_fft,
+                                  int32_t hop_length, int32_t n_mels, int32_t sample_rate, void* stream);
 
 #ifdef __cplusplus
 }

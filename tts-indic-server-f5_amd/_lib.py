@@ -21,6 +21,12 @@ class VocosConfig(C.Structure):
                                           "gemm_planes")]
 
 
+class BigVGANConfig(C.Structure):
+    _fields_ = [("num_mels", C.c_int32), ("num_upsamples", C.c_int32), ("upsample_rates", C.c_int32 * 8),
+                ("upsample_kernel_sizes", C.c_int32 * 8), ("upsample_initial_channel", C.c_int32),
+                ("resblock_kernel_sizes", C.c_int32 * 3), ("resblock_dilations", C.c_int32 * 9), ("gemm_planes", C.c_int32)]
+
+
 # every symbol include/f5hip.h declares: (restype, argtypes)
 SYMBOLS = {
     "f5hip_abi_version": (C.c_int, []),
@@ -42,6 +48,13 @@ SYMBOLS = {
     "f5hip_vocos_load_param": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]),
     "f5hip_vocos_finalize": (C.c_int, [C.c_void_p]),
     "f5hip_vocos_decode": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "f5hip_bigvgan_create": (C.c_void_p, [C.POINTER(BigVGANConfig)]),
+    "f5hip_bigvgan_destroy": (None, [C.c_void_p]),
+    "f5hip_bigvgan_load_param": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]),
+    "f5hip_bigvgan_finalize": (C.c_int, [C.c_void_p]),
+    "f5hip_bigvgan_forward": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "f5hip_mel_spectrogram_bigvgan": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                                C.c_int32, C.c_void_p]),
     "f5hip_mel_spectrogram": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                         C.c_int32, C.c_void_p]),
 }

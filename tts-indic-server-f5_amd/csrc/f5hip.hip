@@ -772,4 +772,5 @@ int f5hip_cfm_sample(f5hip_dit* m, int32_t n_utt, const int32_t* dur, const floa
 }
 
 #include "vocos.h"
+#include "bigvgan.h"
 #include "debug_bench.h"

@@ -42,8 +42,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if constexpr (CONV) {
 #pragma unroll
         for (int i = 0; i < A_RPT; i++) {
-            sstart[i] = p.row_seq_start[m0 + lrow + 64 * i];
-            send[i] = p.row_seq_end[m0 + lrow + 64 * i];
+            const int mr = m0 + lrow + 64 * i;
+            if (p.row_seq_start) {
+                sstart[i] = p.row_seq_start[mr];
+                send[i] = p.row_seq_end[mr];
+            } else {
+                sstart[i] = (mr / p.seq_pitch) * p.seq_pitch;
+                send[i] = sstart[i] + p.seq_valid;
+            }
         }
     }
     const int a_col0 = CONV ? (int)blockIdx.x * p.conv_group_cols : 0;
@@ -66,7 +72,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if constexpr (CONV) {                                                                                  \
             const int tap_ = kt_ / p.conv_kpt;                                                                 \
             a_off_ = (kt_ - tap_ * p.conv_kpt) * 32;                                                           \
-            shift_ = tap_ - p.conv_center;                                                                     \
+            shift_ = (tap_ - p.conv_center) * (p.conv_dil > 1 ? p.conv_dil : 1);                                                                     \
         } else {                                                                                               \
             a_off_ = kt_ * 32;                                                                                 \
         }                                                                                                      \

@@ -20,8 +20,10 @@ struct GemmArgs {
     int conv_kpt;         // k-tiles (of 32 channels) per tap
     int conv_center;      // (kernel_size - 1) / 2
     int conv_group_cols;  // A column base = blockIdx.x * conv_group_cols (grouped conv with BN == group width)
-    const int* row_seq_start;
+    int conv_dil;         // tap spacing in rows (0 is treated as 1): dilated Conv1d
+    const int* row_seq_start;   // per-row sequence bounds, or null: uniform sequences of seq_pitch rows with seq_valid valid ones
     const int* row_seq_end;
+    int seq_pitch, seq_valid;
     int group_w;          // > 0: N is laid out as groups padded to 64 columns; real column = (n/64)*group_w + n%64
     // generic epilogue: v = act(acc + bias); rows with row_keep == 0 -> 0; v = v * mul + res; store fp32 and/or split bf16
     const float* bias;

@@ -81,8 +81,8 @@ static void host_split_bf16(float x, uint16_t& hi, uint16_t& lo) {
 }
 
 // W [N][K] fp32 host (row stride ldw) -> split bf16 device [ceil128(N)][ceil32(K)], bias -> fp32 [ceil128(N)]
-static int pack_linear(PackedW& out, const float* w, int N, int K, int ldw, const float* bias) {
-    out.n = N; out.k = K; out.n_pad = (N + 127) / 128 * 128; out.k_pad = (K + 31) / 32 * 32; out.ld = out.k_pad;
+static int pack_linear(PackedW& out, const float* w, int N, int K, int ldw, const float* bias, int n_align = 128) {
+    out.n = N; out.k = K; out.n_pad = (N + n_align - 1) / n_align * n_align; out.k_pad = (K + 31) / 32 * 32; out.ld = out.k_pad;
     const size_t np = (size_t)out.n_pad * out.k_pad;
     float* tmp = nullptr;
     if (hipMalloc((void**)&tmp, (size_t)N * ldw * sizeof(float)) != hipSuccess) return fail(-4, "hipMalloc pack staging");

@@ -107,19 +107,19 @@ __global__ __launch_bounds__(256) void istft_ola_kernel(const float* fw, const i
 
 // STFT magnitude -> HTK mel filterbank -> log(clamp(., 1e-5)); one block per (frame, batch)
 __global__ __launch_bounds__(256) void mel_frame_kernel(const float* wave, int nw, int T, int hop, int n_mels, const float* window,
-                                                        const float2* tw, const float* fb /*[513][n_mels]*/, float* mel) {
+                                                        const float2* tw, const float* fb /*[513][n_mels]*/, float* mel, int pad, float mag_eps) {
     __shared__ float2 s[1024];
     __shared__ float mag[520];
     const int t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     const float* w = wave + (size_t)b * nw;
     for (int n = tid; n < 1024; n += 256) {
-        int idx = t * hop - 512 + n;               // center=True, pad_mode="reflect"
+        int idx = t * hop - pad + n;               // reflect padding by `pad` samples on both sides
         if (idx < 0) idx = -idx;
         if (idx >= nw) idx = 2 * (nw - 1) - idx;
         s[__brev((unsigned)n) >> 22] = make_float2(w[idx] * window[n], 0.0f);
     }
     fft1024_lds(s, tw, tid, -1.0f);
-    for (int k = tid; k <= 512; k += 256) mag[k] = sqrtf(s[k].x * s[k].x + s[k].y * s[k].y);   // power = 1
+    for (int k = tid; k <= 512; k += 256) mag[k] = sqrtf(s[k].x * s[k].x + s[k].y * s[k].y + mag_eps);   // power = 1
     __syncthreads();
     if (tid < n_mels) {
         float acc = 0.0f;
@@ -340,8 +340,50 @@ int f5hip_mel_spectrogram(int32_t batch, int32_t n_samples, const float* wave_de
     const int T = 1 + n_samples / hop_length;
     prof_begin(PROF_OTHER, st);
     hipLaunchKernelGGL(mel_frame_kernel, dim3(T, batch), dim3(256), 0, st, wave_dev, n_samples, T, hop_length, n_mels, g_mel.window,
-                       g_mel.twiddle, g_mel.fb, mel_dev);
+                       g_mel.twiddle, g_mel.fb, mel_dev, n_fft / 2, 0.0f);
     prof_end(PROF_OTHER, st);
     CKL("mel_frame");
+    return 0;
+}
+
+// ---- BigVGAN-style mel (F/model/modules.py:30-72): librosa Slaney filterbank, center=False after a reflect pad of (n_fft - hop) / 2
+static MelTables g_mel_bv;
+
+int f5hip_mel_spectrogram_bigvgan(int32_t batch, int32_t n_samples, const float* wave_dev, float* mel_dev, int32_t n_fft, int32_t hop_length,
+                                  int32_t n_mels, int32_t sample_rate, void* stream) {
+    if (batch <= 0 || n_samples < n_fft || !wave_dev || !mel_dev) return fail(-1, "mel_spectrogram_bigvgan: bad argument");
+    if (n_fft != 1024 || n_mels > 256) return fail(-1, "mel_spectrogram_bigvgan: only n_fft = 1024, n_mels <= 256");
+    hipStream_t st = (hipStream_t)stream;
+    if (g_mel_bv.n_fft != n_fft || g_mel_bv.n_mels != n_mels || g_mel_bv.sr != sample_rate) {
+        dev_free(g_mel_bv.window); dev_free(g_mel_bv.twiddle); dev_free(g_mel_bv.fb);
+        g_mel_bv = MelTables();
+        if (make_fft_tables(&g_mel_bv.window, &g_mel_bv.twiddle, n_fft)) return -4;
+        // librosa.filters.mel(sr, n_fft, n_mels, fmin=0, fmax=sr/2, htk=False, norm="slaney")
+        const int nf = n_fft / 2 + 1;
+        const double f_sp = 200.0 / 3, min_log_hz = 1000.0, min_log_mel = min_log_hz / f_sp, logstep = log(6.4) / 27.0;
+        auto hz_to_mel = [&](double f) { return f >= min_log_hz ? min_log_mel + log(f / min_log_hz) / logstep : f / f_sp; };
+        auto mel_to_hz = [&](double m) { return m >= min_log_mel ? min_log_hz * exp(logstep * (m - min_log_mel)) : f_sp * m; };
+        const double fmax = sample_rate / 2.0, m0 = hz_to_mel(0.0), m1 = hz_to_mel(fmax);
+        std::vector<double> mf(n_mels + 2);
+        for (int i = 0; i < n_mels + 2; i++) mf[i] = mel_to_hz(m0 + (m1 - m0) * (double)i / (double)(n_mels + 1));
+        std::vector<float> fb((size_t)nf * n_mels, 0.0f);
+        for (int k = 0; k < nf; k++) {
+            const double f = fmax * (double)k / (double)(nf - 1);
+            for (int j = 0; j < n_mels; j++) {
+                const double lower = (f - mf[j]) / (mf[j + 1] - mf[j]), upper = (mf[j + 2] - f) / (mf[j + 2] - mf[j + 1]);
+                const double w = std::max(0.0, std::min(lower, upper)) * (2.0 / (mf[j + 2] - mf[j]));
+                fb[(size_t)k * n_mels + j] = (float)w;
+            }
+        }
+        if (upload_f32(&g_mel_bv.fb, fb.data(), fb.size())) return -4;
+        g_mel_bv.n_fft = n_fft; g_mel_bv.n_mels = n_mels; g_mel_bv.sr = sample_rate;
+    }
+    const int pad = (n_fft - hop_length) / 2;
+    const int T = (n_samples + 2 * pad - n_fft) / hop_length + 1;
+    prof_begin(PROF_OTHER, st);
+    hipLaunchKernelGGL(mel_frame_kernel, dim3(T, batch), dim3(256), 0, st, wave_dev, n_samples, T, hop_length, n_mels, g_mel_bv.window,
+                       g_mel_bv.twiddle, g_mel_bv.fb, mel_dev, pad, 1e-9f);
+    prof_end(PROF_OTHER, st);
+    CKL("mel_frame (bigvgan)");
     return 0;
 }

@@ -142,9 +142,10 @@ class F5HipModel:
         `torch.randn(dur, mel)` from the global CPU generator)."""
         if duplicate_test:
             raise NotImplementedError("duplicate_test is a debugging corner of the reference that is out of scope")
-        if cond.ndim == 2:   # raw wave -> mel (cfm.py:103-106)
-            from .mel import mel_spectrogram
-            cond = mel_spectrogram(cond.to(self.device, torch.float32)).permute(0, 2, 1)
+        if cond.ndim == 2:   # raw wave -> mel (cfm.py:103-106) with the extractor of mel_spec_type (modules.py:123-126)
+            from .mel import mel_spectrogram, mel_spectrogram_bigvgan
+            fe = mel_spectrogram_bigvgan if self.mel_spec_type == "bigvgan" else mel_spectrogram
+            cond = fe(cond.to(self.device, torch.float32)).permute(0, 2, 1)
             assert cond.shape[-1] == self.num_channels
         cond = cond.to(self.device, torch.float32)
         batch, cond_seq_len = cond.shape[:2]

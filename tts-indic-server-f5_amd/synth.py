@@ -103,6 +103,34 @@ def vocos_param_specs(in_ch=100, dim=512, inter=1536, layers=8, n_fft=1024):
     return s
 
 
+def bigvgan_param_specs(num_mels=100, upsample_rates=(4, 4, 2, 2, 2, 2), upsample_kernel_sizes=(8, 8, 4, 4, 4, 4),
+                        upsample_initial_channel=1536, resblock_kernel_sizes=(3, 7, 11), n_dil=3):
+    """Ordered (name, shape, kind) list of the BigVGAN v2 generator after remove_weight_norm()."""
+    c0 = upsample_initial_channel
+    s = [("conv_pre.weight", (c0, num_mels, 7), "conv"), ("conv_pre.bias", (c0,), "bias")]
+    for i, (r, k) in enumerate(zip(upsample_rates, upsample_kernel_sizes)):
+        ci, co = c0 // 2 ** i, c0 // 2 ** (i + 1)
+        s += [(f"ups.{i}.0.weight", (ci, co, k), "convT"), (f"ups.{i}.0.bias", (co,), "bias")]
+    for i in range(len(upsample_rates)):
+        ch = c0 // 2 ** (i + 1)
+        for j, k in enumerate(resblock_kernel_sizes):
+            q = f"resblocks.{i * len(resblock_kernel_sizes) + j}."
+            for d in range(n_dil):
+                s += [(f"{q}convs1.{d}.weight", (ch, ch, k), "conv_res"), (f"{q}convs1.{d}.bias", (ch,), "bias")]
+            for d in range(n_dil):
+                s += [(f"{q}convs2.{d}.weight", (ch, ch, k), "conv_res"), (f"{q}convs2.{d}.bias", (ch,), "bias")]
+            for a in range(2 * n_dil):
+                s += [(f"{q}activations.{a}.act.alpha", (ch,), "snake"), (f"{q}activations.{a}.act.beta", (ch,), "snake")]
+    ch = c0 // 2 ** len(upsample_rates)
+    s += [("activation_post.act.alpha", (ch,), "snake"), ("activation_post.act.beta", (ch,), "snake"),
+          ("conv_post.weight", (1, ch, 7), "conv_post")]
+    return s
+
+
+def bigvgan_state_dict(seed=SEED_BIGVGAN, **arch):
+    return make_state_dict(bigvgan_param_specs(**arch), seed)
+
+
 def _draw(shape, kind, g):
     if kind in ("linear", "adaln"):
         return torch.randn(shape, generator=g) / math.sqrt(shape[1])
@@ -110,6 +138,14 @@ def _draw(shape, kind, g):
         return torch.randn(shape, generator=g) / math.sqrt(shape[1] * shape[2])
     if kind == "embed":
         return torch.randn(shape, generator=g)
+    if kind == "convT":      # ConvTranspose1d weight [c_in, c_out, k]: each output sees c_in * k / stride taps
+        return torch.randn(shape, generator=g) / math.sqrt(shape[0] * shape[2] / 2.0)
+    if kind == "conv_res":   # residual-branch convs: half gain keeps the 18 residual adds per stage O(1)
+        return torch.randn(shape, generator=g) * (0.5 / math.sqrt(shape[1] * shape[2]))
+    if kind == "snake":      # log-scale alpha / beta around 0 (= 1 in linear scale)
+        return torch.randn(shape, generator=g) * 0.2
+    if kind == "conv_post":
+        return torch.randn(shape, generator=g) * (0.2 / math.sqrt(shape[1] * shape[2]))
     if kind == "bias":
         return torch.randn(shape, generator=g) * 0.02
     if kind == "adaln_bias":  # non-zero so shift/scale/gate are O(0.3) and every branch is exercised
