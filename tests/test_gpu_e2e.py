@@ -1,0 +1,62 @@
+"""GPU end-to-end through the level-2 boundary: infer_process(ref_audio, ref_text, gen_text, model_obj, vocoder) on the HIP
+objects vs the same host glue driving the CPU oracle (mel front-end -> CFM.sample -> Vocos), multi-chunk text incl. the
+cross-fade, quiet reference (rms gain branch) and string tokenisation through a vocab."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import dit_oracle as O  # noqa: E402
+from oracle import vocos_oracle as V  # noqa: E402
+from tts_indic_server_f5_amd import infer, synth  # noqa: E402
+from tts_indic_server_f5_amd.tokenizer import list_str_to_idx  # noqa: E402
+
+ARCH = dict(dim=256, depth=4, heads=4, ff_mult=2, text_dim=64, conv_layers=2, text_num_embeds=96)
+VOCAB = {chr(32 + i): i for i in range(96)}   # printable ASCII, " " -> 0
+
+
+class OracleModel:
+    """CFM.sample semantics on the CPU oracle (raw-wave cond -> oracle mel; list[str] text -> vocab lookup)."""
+
+    def __init__(self, sd):
+        self.sd, self.cfg = sd, O.DiTConfig(**ARCH)
+
+    def sample(self, cond, text, duration, steps, cfg_strength, sway_sampling_coef):
+        mel = V.vocos_mel_spectrogram(cond.cpu()).permute(0, 2, 1)
+        ids = list_str_to_idx(text, VOCAB)
+        out, _ = O.cfm_sample(self.sd, self.cfg, mel, ids, duration, steps=steps, cfg_strength=cfg_strength,
+                              sway_sampling_coef=sway_sampling_coef, seed=None, keep_trajectory=False)
+        return out, None
+
+
+class OracleVocoder:
+    def __init__(self, sd):
+        self.sd = sd
+
+    def decode(self, mel):
+        return V.vocos_decode(self.sd, mel.cpu())
+
+
+@pytest.mark.parametrize("amp", [0.15, 0.03])
+def test_infer_process_matches_oracle_pipeline(amp):
+    from tts_indic_server_f5_amd.model import DiTArch, F5HipModel
+    from tts_indic_server_f5_amd.vocoder import F5HipVocos
+    sd, vsd = synth.dit_state_dict(**ARCH), synth.vocos_state_dict()
+    ref_audio = (synth.ref_audio(24000 * 2, amp=amp), 24000)
+    ref_text = "Some call me nature."
+    gen_text = "I do not care what you call me. I have been a silent spectator, watching species evolve. Always remember, I endure."
+    kw = dict(nfe_step=8, cfg_strength=2.0, sway_sampling_coef=-1.0)
+    hip_model = F5HipModel(DiTArch(**ARCH), sd, vocab_char_map=VOCAB)
+    hip_voc = F5HipVocos(vsd)
+    torch.manual_seed(123)   # the reference draws the noise from the global CPU generator (cfm.py:181-186)
+    w_hip, sr, spec_hip = infer.infer_process(ref_audio, ref_text, gen_text, hip_model, hip_voc, device="cuda", **kw)
+    torch.manual_seed(123)
+    w_ref, _, spec_ref = infer.infer_process(ref_audio, ref_text, gen_text, OracleModel(sd), OracleVocoder(vsd), **kw)
+    assert sr == 24000 and w_hip.shape == w_ref.shape and spec_hip.shape == spec_ref.shape
+    assert spec_hip.shape[0] == 100 and len(infer.chunk_text(gen_text, max_chars=int(len(ref_text.encode()) / 2 * 23))) >= 1
+    mel_rms = float(np.sqrt(np.mean((spec_hip - spec_ref) ** 2)))
+    wav_max = float(np.max(np.abs(w_hip - w_ref)))
+    print(f"[parity] e2e amp={amp}: mel rms err {mel_rms:.3e}  wave max err {wav_max:.3e}  wave rms {np.sqrt(np.mean(w_ref ** 2)):.3e}  n={len(w_ref)}")
+    assert mel_rms < 1e-3
+    assert wav_max < 2e-3   # end to end the 1e-4 mel error passes through exp() in the ISTFT head; vocoder-only parity is 1e-6
