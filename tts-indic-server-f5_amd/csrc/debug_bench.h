@@ -16,18 +16,19 @@ extern "C" int f5hip_debug_gemm_stamps(int32_t M, int32_t N, int32_t K, int32_t 
     size_t na = (size_t)M * K, nw = (size_t)N * K, no = (size_t)M * N;
     unsigned long long* dst = nullptr;
     if (hipMalloc(&fa, na * 4) || hipMalloc(&fw, nw * 4) || hipMalloc(&A.hi, na * 2) || hipMalloc(&A.lo, na * 2) || hipMalloc(&O.hi, no * 2) ||
-        hipMalloc(&O.lo, no * 2) || hipMalloc(&W.hi, nw * 2) || hipMalloc(&W.lo, nw * 2) || hipMalloc(&dst, 64)) return fail(-5, "stamps: hipMalloc");
+        hipMalloc(&O.lo, no * 2) || hipMalloc(&W.hi, nw * 2) || hipMalloc(&W.lo, nw * 2) || hipMalloc(&dst, 128)) return fail(-5, "stamps: hipMalloc");
     hipLaunchKernelGGL(fill_pattern_kernel, dim3((na + 255) / 256), dim3(256), 0, 0, fa, na, 1u);
     hipLaunchKernelGGL(fill_pattern_kernel, dim3((nw + 255) / 256), dim3(256), 0, 0, fw, nw, 2u);
     hipLaunchKernelGGL(pack_weight_kernel, dim3(M), dim3(256), 0, 0, fa, M, K, K, A.hi, A.lo, K);
     hipLaunchKernelGGL(pack_weight_kernel, dim3(N), dim3(256), 0, 0, fw, N, K, K, W.hi, W.lo, K);
     W.n = N; W.k = K; W.n_pad = N; W.k_pad = K; W.ld = K; W.bias = nullptr;
     GemmArgs a = gemm_base(A, K, W, M);
-    a.act = ACT_GELU_TANH; a.out_hi = O.hi; a.out_lo = O.lo; a.ldob = N; a.stamps = dst; a.stamp_bx = bx; a.stamp_by = by;
+    a.act = ACT_GELU_TANH; a.out_hi = O.hi; a.out_lo = O.lo; a.ldob = N; a.stamps = dst;
+    if (bx < 0) { bx = -bx - 1; a.act = ACT_NONE; a.out_hi = nullptr; a.out_lo = nullptr; hipMalloc(&a.out_f32, no * 4); a.ldo = N; a.res = a.out_f32; a.ldres = N; } a.stamp_bx = bx; a.stamp_by = by;
     hipError_t e = hipSuccess;
     for (int it = 0; it < 3; it++) e = bn == 128 ? launch_gemm_t<2, 128, false, EPI_GENERIC, 3>(a, M, N, 0) : launch_gemm_t<2, 64, false, EPI_GENERIC, 3>(a, M, N, 0);
     hipDeviceSynchronize();
-    hipMemcpy(out, dst, 56, hipMemcpyDeviceToHost);
+    hipMemcpy(out, dst, 88, hipMemcpyDeviceToHost);
     for (void* p : {(void*)fa, (void*)fw, (void*)A.hi, (void*)A.lo, (void*)O.hi, (void*)O.lo, (void*)W.hi, (void*)W.lo, (void*)dst}) hipFree(p);
     if (e != hipSuccess) return fail(-7, "stamps launch: %s", hipGetErrorString(e));
     return 0;

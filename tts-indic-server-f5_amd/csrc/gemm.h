@@ -171,12 +171,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #undef STORE_TILES
 
     // ---------------------------------------------------------------- epilogue (gemm_epilogue.h)
-    gemm_epilogue<EPI, TM, TN>(p, acc, reinterpret_cast<float*>(smem) + wave * 2048, m0 + wm * (TM * 32), n0 + wn * 64, n0, lane);
+    unsigned long long epi_dbg[4] = {0, 0, 0, 0};
+    gemm_epilogue<EPI, TM, TN>(p, acc, reinterpret_cast<float*>(smem) + wave * (TM * TN * 1024), m0 + wm * (TM * 32), n0 + wn * 64, n0, lane,
+                               ABL == 3 ? epi_dbg : nullptr);
     STAMP(5);   // epilogue
     if constexpr (ABL == 3) {
         if (p.stamps && blockIdx.x == p.stamp_bx && blockIdx.y == p.stamp_by && tid == 0) {
             for (int i = 0; i < 6; i++) p.stamps[i] = st_acc[i];
             p.stamps[6] = st_prev - st_begin;
+            for (int i = 0; i < 4; i++) p.stamps[7 + i] = epi_dbg[i];
         }
     }
 #undef STAMP
@@ -184,7 +187,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 template <int NSPLIT, int BN, bool CONV, int EPI, int ABL = 0>
 static hipError_t launch_gemm_t(const GemmArgs& a, int m_pad, int n_pad, hipStream_t st) {
-    constexpr int LDS = 2 * NSPLIT * (128 + BN) * 64 < 32768 ? 32768 : 2 * NSPLIT * (128 + BN) * 64;   // >= 4 x 8 KB epilogue slabs
+    constexpr int EPI_LDS = (128 / (4 / (BN / 64)) / 32) * 2 * 4096 * 4;   // 4 waves x (TM x TN) x 4 KiB epilogue slabs
+    constexpr int LDS = 2 * NSPLIT * (128 + BN) * 64 < EPI_LDS ? EPI_LDS : 2 * NSPLIT * (128 + BN) * 64;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<NSPLIT, BN, CONV, EPI, ABL>),

@@ -26,9 +26,9 @@ struct Gemm2Cfg {
     static constexpr int NST = (4 * STAGE <= 144 * 1024) ? 4 : 3;
     static constexpr int PIECES = STAGE / 1024;   // 1 KiB LDS-DMA pieces per stage
     static constexpr int P = PIECES / 8;          // per wave
-    static constexpr int LDS = NST * STAGE;
+    static constexpr int LDS = NST * STAGE > 8 * TM * TN * 4096 ? NST * STAGE : 8 * TM * TN * 4096;   // ring, and room for the epilogue slabs
     static_assert(PIECES % 8 == 0, "pieces must divide over 8 waves");
-    static_assert(LDS >= 8 * 32 * 32 * TN * 4, "ring must hold the epilogue slabs");
+    static_assert(LDS >= 8 * TM * TN * 4096, "ring must hold the epilogue slabs");
 };
 
 template <int N>
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 }
         }
     }
-    gemm_epilogue<EPI, TM, TN>(p, acc, reinterpret_cast<float*>(smem) + wave * (32 * 32 * TN), m0 + wm * (TM * 32), n0 + wn * (TN * 32), n0,
+    gemm_epilogue<EPI, TM, TN>(p, acc, reinterpret_cast<float*>(smem) + wave * (TM * TN * 1024), m0 + wm * (TM * 32), n0 + wn * (TN * 32), n0,
                                lane);
 }
 

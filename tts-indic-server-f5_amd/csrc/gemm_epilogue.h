@@ -50,10 +50,12 @@ struct GemmArgs {
     int stamp_bx, stamp_by;
 };
 
-// one 32 x WN slice staged in `stg` (fp32, row stride WN): generic epilogue, lane owns 4 columns of 32 / RPP rows
-template <int ACT, int WN>
-F5_DEVICE void epi_generic_rows(const GemmArgs& p, const float* stg, int m_base, int n_base, int lane) {
-    constexpr int LPR = WN / 4, RPP = 64 / LPR, NQ = 32 / RPP;
+// one 32 x WN slice staged in `stg` (fp32, row stride WN): generic epilogue, lane owns 4 columns of 32 / RPP rows.
+// RES / OUTF / OUTS (residual present, fp32 output, split-bf16 output) are compile-time so the hot variants carry no
+// per-element pointer tests; row pointers advance incrementally (one 64-bit add per row group instead of a 64-bit multiply).
+template <int ACT, int WN, int ROWS, bool RES, bool OUTF, bool OUTS>
+F5_DEVICE void epi_generic_rows_t(const GemmArgs& p, const float* stg, int m_base, int n_base, int lane) {
+    constexpr int LPR = WN / 4, RPP = 64 / LPR, NQ = ROWS / RPP;
     const int c4 = (lane % LPR) * 4, r0 = lane / LPR;
     const int n = n_base + c4;   // column in the (possibly group-padded) weight layout
     int no = n;                  // column in the output / residual / multiplier
@@ -65,19 +67,25 @@ F5_DEVICE void epi_generic_rows(const GemmArgs& p, const float* stg, int m_base,
     f32x4 bv = {0.f, 0.f, 0.f, 0.f}, mv = {1.f, 1.f, 1.f, 1.f};
     if (p.bias && nok) bv = *reinterpret_cast<const f32x4*>(p.bias + n);
     if (p.mul && nok) mv = *reinterpret_cast<const f32x4*>(p.mul + no);
+    const int mrow = m_base + r0;
+    const float* rp = RES ? p.res + (size_t)mrow * p.ldres + no : nullptr;
     f32x4 rs[NQ];
     int keep[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; q++) {
-        const int m = m_base + q * RPP + r0;
         rs[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
         keep[q] = 1;
-        if (p.res && nok && m < p.M) rs[q] = *reinterpret_cast<const f32x4*>(p.res + (size_t)m * p.ldres + no);
-        if (p.row_keep) keep[q] = p.row_keep[m];
+        if (RES) {
+            if (nok && mrow + q * RPP < p.M) rs[q] = *reinterpret_cast<const f32x4*>(rp + (size_t)q * RPP * p.ldres);
+        }
+        if (p.row_keep) keep[q] = p.row_keep[mrow + q * RPP];
     }
+    float* of = OUTF ? p.out_f32 + (size_t)mrow * p.ldo + no : nullptr;
+    __bf16* oh = OUTS ? p.out_hi + (size_t)mrow * p.ldob + no : nullptr;
+    __bf16* ol = OUTS && p.out_lo ? p.out_lo + (size_t)mrow * p.ldob + no : nullptr;
+    const size_t sf = (size_t)RPP * p.ldo, sb = (size_t)RPP * p.ldob;
 #pragma unroll
     for (int q = 0; q < NQ; q++) {
-        const int m = m_base + q * RPP + r0;
         f32x4 v = *reinterpret_cast<const f32x4*>(stg + (q * RPP + r0) * WN + c4) + bv;
         if (ACT != ACT_NONE) {
 #pragma unroll
@@ -85,24 +93,45 @@ F5_DEVICE void epi_generic_rows(const GemmArgs& p, const float* stg, int m_base,
         }
         if (!keep[q]) v = (f32x4){0.f, 0.f, 0.f, 0.f};
         v = v * mv + rs[q];
-        if (nok && m < p.M) {
-            if (p.out_f32) *reinterpret_cast<f32x4*>(p.out_f32 + (size_t)m * p.ldo + no) = v;
-            if (p.out_hi) {
+        if (nok && mrow + q * RPP < p.M) {
+            if (OUTF) *reinterpret_cast<f32x4*>(of + q * sf) = v;
+            if (OUTS) {
                 bf16x4 hi, lo;
                 const float vv[4] = {v[0], v[1], v[2], v[3]};
                 split_bf16x4(vv, hi, lo);
-                *reinterpret_cast<bf16x4*>(p.out_hi + (size_t)m * p.ldob + no) = hi;
-                if (p.out_lo) *reinterpret_cast<bf16x4*>(p.out_lo + (size_t)m * p.ldob + no) = lo;
+                *reinterpret_cast<bf16x4*>(oh + q * sb) = hi;
+                if (ol) *reinterpret_cast<bf16x4*>(ol + q * sb) = lo;
             }
         }
     }
 }
 
+template <int ACT, int WN, int ROWS>
+F5_DEVICE void epi_generic_rows(const GemmArgs& p, const float* stg, int m_base, int n_base, int lane) {
+    const bool res = p.res != nullptr, outf = p.out_f32 != nullptr, outs = p.out_hi != nullptr;
+    if (ACT == ACT_NONE) {   // residual / plain projections: every output combination occurs
+        if (res) {
+            if (outf && outs) epi_generic_rows_t<ACT, WN, ROWS, true, true, true>(p, stg, m_base, n_base, lane);
+            else if (outf) epi_generic_rows_t<ACT, WN, ROWS, true, true, false>(p, stg, m_base, n_base, lane);
+            else epi_generic_rows_t<ACT, WN, ROWS, true, false, true>(p, stg, m_base, n_base, lane);
+        } else {
+            if (outf && outs) epi_generic_rows_t<ACT, WN, ROWS, false, true, true>(p, stg, m_base, n_base, lane);
+            else if (outf) epi_generic_rows_t<ACT, WN, ROWS, false, true, false>(p, stg, m_base, n_base, lane);
+            else epi_generic_rows_t<ACT, WN, ROWS, false, false, true>(p, stg, m_base, n_base, lane);
+        }
+    } else {                 // activations: (no residual -> split or fp32) and (residual -> fp32) are the combinations in use
+        if (res) epi_generic_rows_t<ACT, WN, ROWS, true, true, false>(p, stg, m_base, n_base, lane);
+        else if (outs && !outf) epi_generic_rows_t<ACT, WN, ROWS, false, false, true>(p, stg, m_base, n_base, lane);
+        else if (outf && !outs) epi_generic_rows_t<ACT, WN, ROWS, false, true, false>(p, stg, m_base, n_base, lane);
+        else epi_generic_rows_t<ACT, WN, ROWS, false, true, true>(p, stg, m_base, n_base, lane);
+    }
+}
+
 // Q / K blocks of the fused QKV projection: bias, rotary embedding on head 0 (x-transformers interleaved pairs, applied
 // before the head split: F/model/modules.py:414-419), q * 1/8 (softmax scale, exact in bf16), bf16 row-major [M][2 D]
-template <int WN>
+template <int WN, int ROWS>
 F5_DEVICE void epi_qk_rows(const GemmArgs& p, const float* stg, int m_base, int n_base, int lane) {
-    constexpr int LPR = WN / 4, RPP = 64 / LPR, NQ = 32 / RPP;
+    constexpr int LPR = WN / 4, RPP = 64 / LPR, NQ = ROWS / RPP;
     const int c4 = (lane % LPR) * 4, r0 = lane / LPR;
     const int n = n_base + c4;
     const int D = p.D;
@@ -137,21 +166,34 @@ F5_DEVICE void epi_qk_rows(const GemmArgs& p, const float* stg, int m_base, int 
     }
 }
 
-// Whole-wave epilogue.  `slab` = wave-private LDS (32 * 32 * TN floats); m_wave / n_wave = first row / (padded) column of
+// Whole-wave epilogue.  `slab` = wave-private LDS (32 TM x 32 TN floats); m_wave / n_wave = first row / (padded) column of
 // the wave's sub-tile; n_blk = first column of the workgroup tile (uniform per workgroup, selects q/k vs v).
 // Every wave of the workgroup must call this: one workgroup barrier protects the k-loop stages the slabs alias; after it
 // the slab is wave-private, DS operations of one wave execute in order, so a wavefront-scope fence (compiler ordering
-// only, no instruction) is all that separates the transposing writes from the row reads.
+// only, no instruction) is all that separates the transposing writes from the row reads.  The whole sub-tile is staged
+// at once so the accumulators are dead before the row phase (its residual prefetch needs their registers).
 template <int EPI, int TM, int TN>
-F5_DEVICE void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[TM][TN], float* slab, int m_wave, int n_wave, int n_blk, int lane) {
-    constexpr int WN = TN * 32;
+F5_DEVICE void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[TM][TN], float* slab, int m_wave, int n_wave, int n_blk, int lane,
+                              unsigned long long* dbg = nullptr) {
+    constexpr int WN = TN * 32, ROWS = TM * 32;
+    unsigned long long dprev = 0;
+#define EPI_STAMP(IDX)                                                                               \
+    if (dbg) {                                                                                       \
+        unsigned long long t_;                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                           \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                  \
+        __builtin_amdgcn_sched_barrier(0);                                                           \
+        if ((IDX) >= 0) dbg[(IDX)] += t_ - dprev;                                                    \
+        dprev = t_;                                                                                  \
+    }
+    EPI_STAMP(-1);
     const int fr = lane & 31, fh = lane >> 5;
     __syncthreads();
+    EPI_STAMP(0);
+    if (EPI == EPI_QKV && n_blk >= 2 * p.D) {
+        // V block: written transposed ([feature][token]) straight from the accumulators, 4 tokens = 8 bytes per store
 #pragma unroll
-    for (int i = 0; i < TM; i++) {
-        const int m_base = m_wave + i * 32;
-        if (EPI == EPI_QKV && n_blk >= 2 * p.D) {
-            // V block: written transposed ([feature][token]) straight from the accumulators, 4 tokens = 8 bytes per store
+        for (int i = 0; i < TM; i++)
 #pragma unroll
             for (int j = 0; j < TN; j++) {
                 const int nd = n_wave - 2 * p.D + j * 32 + fr;
@@ -161,27 +203,31 @@ F5_DEVICE void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[TM][TN], float* sl
                     bf16x4 pk;
 #pragma unroll
                     for (int e = 0; e < 4; e++) pk[e] = (__bf16)(acc[i][j][a4 * 4 + e] + bv);
-                    *reinterpret_cast<bf16x4*>(p.vt + (size_t)nd * p.ldvt + m_base + 8 * a4 + 4 * fh) = pk;
+                    *reinterpret_cast<bf16x4*>(p.vt + (size_t)nd * p.ldvt + m_wave + i * 32 + 8 * a4 + 4 * fh) = pk;
                 }
             }
-            continue;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; i++)
 #pragma unroll
         for (int j = 0; j < TN; j++)
 #pragma unroll
-            for (int g = 0; g < 16; g++) slab[((g & 3) + 8 * (g >> 2) + 4 * fh) * WN + j * 32 + fr] = acc[i][j][g];
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        if (EPI == EPI_GENERIC) {
-            switch (p.act) {
-                case ACT_GELU_TANH: epi_generic_rows<ACT_GELU_TANH, WN>(p, slab, m_base, n_wave, lane); break;
-                case ACT_GELU_ERF: epi_generic_rows<ACT_GELU_ERF, WN>(p, slab, m_base, n_wave, lane); break;
-                case ACT_MISH: epi_generic_rows<ACT_MISH, WN>(p, slab, m_base, n_wave, lane); break;
-                case ACT_SILU: epi_generic_rows<ACT_SILU, WN>(p, slab, m_base, n_wave, lane); break;
-                default: epi_generic_rows<ACT_NONE, WN>(p, slab, m_base, n_wave, lane); break;
-            }
-        } else {
-            epi_qk_rows<WN>(p, slab, m_base, n_wave, lane);
+            for (int g = 0; g < 16; g++) slab[(i * 32 + (g & 3) + 8 * (g >> 2) + 4 * fh) * WN + j * 32 + fr] = acc[i][j][g];
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    EPI_STAMP(1);
+    if (EPI == EPI_GENERIC) {
+        switch (p.act) {
+            case ACT_GELU_TANH: epi_generic_rows<ACT_GELU_TANH, WN, ROWS>(p, slab, m_wave, n_wave, lane); break;
+            case ACT_GELU_ERF: epi_generic_rows<ACT_GELU_ERF, WN, ROWS>(p, slab, m_wave, n_wave, lane); break;
+            case ACT_MISH: epi_generic_rows<ACT_MISH, WN, ROWS>(p, slab, m_wave, n_wave, lane); break;
+            case ACT_SILU: epi_generic_rows<ACT_SILU, WN, ROWS>(p, slab, m_wave, n_wave, lane); break;
+            default: epi_generic_rows<ACT_NONE, WN, ROWS>(p, slab, m_wave, n_wave, lane); break;
         }
+    } else {
+        epi_qk_rows<WN, ROWS>(p, slab, m_wave, n_wave, lane);
     }
+    EPI_STAMP(2);
+    if (dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); EPI_STAMP(3); }   // drain of the outstanding stores
+#undef EPI_STAMP
 }
