@@ -11,11 +11,11 @@ fn.argtypes = [C.c_int32] * 7 + [C.POINTER(C.c_double)]
 torch.cuda.init()
 shapes = [("qkv-like", 2816, 3072, 1024), ("ff1", 2816, 2048, 1024), ("ff2", 2816, 1024, 2048), ("out", 2816, 1024, 1024),
           ("big", 22528, 2048, 1024), ("4096^3", 4096, 4096, 4096)]
-names = {20: "gemm2 128x128", 21: "gemm2 256x128", 100: "normal +pad", 101: "no-gload +pad", 102: "no-mfma +pad", 0: "normal", 1: "no-gload", 2: "no-mfma", 10: "normal f32-rmw epi", 11: "no-gload f32 epi", 12: "no-mfma f32 epi"}
+names = {30: "gemm3 warp-spec", 20: "gemm2 128x128", 21: "gemm2 256x128", 100: "normal +pad", 101: "no-gload +pad", 102: "no-mfma +pad", 0: "normal", 1: "no-gload", 2: "no-mfma", 10: "normal f32-rmw epi", 11: "no-gload f32 epi", 12: "no-mfma f32 epi"}
 for nm, M, N, K in shapes:
     for planes in (2, 1):
         for bn in (128, 64):
-            for var in ((0, 1, 20, 21) if bn == 128 else (0,)):
+            for var in ((0, 20, 30) if bn == 128 else (0,)):
                 us = C.c_double(0)
                 rc = fn(M, N, K, planes, bn, var, 20, C.byref(us))
                 if rc:

@@ -60,6 +60,7 @@ extern "C" int f5hip_debug_gemm_bench(int32_t M, int32_t N, int32_t K, int32_t p
     for (int it = -2; it < iters; it++) {
         if (it == 0) hipEventRecord(e0, 0);
         if (variant == 20) e = planes == 2 ? launch_gemm2_t<2, 128, 128, EPI_GENERIC>(a, M, N, 0) : launch_gemm2_t<1, 128, 128, EPI_GENERIC>(a, M, N, 0);
+        else if (variant == 30) e = planes == 2 ? launch_gemm3_t<2, EPI_GENERIC>(a, M, N, 0) : launch_gemm3_t<1, EPI_GENERIC>(a, M, N, 0);
         else if (variant == 21) e = planes == 2 ? launch_gemm2_t<2, 256, 128, EPI_GENERIC>(a, M, N, 0) : launch_gemm2_t<1, 256, 128, EPI_GENERIC>(a, M, N, 0);
         else if (planes == 2 && bn == 128) {
             if (variant == 0) e = launch_gemm_t<2, 128, false, EPI_GENERIC, 0>(a, M, N, 0);

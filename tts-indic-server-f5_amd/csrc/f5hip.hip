@@ -17,6 +17,7 @@
 #include "elementwise.h"
 #include "gemm.h"
 #include "gemm2.h"
+#include "gemm3.h"
 #include "host_util.h"
 
 // =================================================================================================
@@ -401,7 +402,11 @@ static int run_gemm_n(int nsplit, int mp, GemmArgs& a, const PackedW& W, int epi
     // 4-wave workgroups hide each other's prologue / epilogue and win.  F5HIP_GEMM_IMPL=1 / 2 forces one kernel.
     const long long tiles128 = (long long)(mp / 128) * (np / 128);
     const bool use2 = !conv && (g_gemm_impl == 2 || (g_gemm_impl == 0 && tiles128 <= 256 && epi != EPI_QKV));
-    if (use2) {
+    const bool use3 = !conv && (g_gemm_impl == 3 || (g_gemm_impl == 0 && tiles128 <= 256 && epi != EPI_QKV));
+    if (use3) {   // warp-specialised producer / consumer kernel: one tile per CU finishes soonest on it (microbench: 30.5 vs 31.0 vs 41 us)
+        if (nsplit == 2) e = epi == EPI_QKV ? launch_gemm3_t<2, EPI_QKV>(a, mp, np, st) : launch_gemm3_t<2, EPI_GENERIC>(a, mp, np, st);
+        else e = epi == EPI_QKV ? launch_gemm3_t<1, EPI_QKV>(a, mp, np, st) : launch_gemm3_t<1, EPI_GENERIC>(a, mp, np, st);
+    } else if (use2) {
         const bool big = mp % 256 == 0 && tiles128 >= 4 * 256 && epi != EPI_QKV;
         if (nsplit == 2) {
             if (epi == EPI_QKV) e = launch_gemm2_t<2, 128, 128, EPI_QKV>(a, mp, np, st);

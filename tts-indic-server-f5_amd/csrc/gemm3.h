@@ -1,0 +1,137 @@
+// gemm3: warp-specialised split-bf16 MFMA GEMM for gfx950 (128 x 128 x 32 tiles, one 512-thread workgroup per CU).
+//
+// In-kernel s_memtime stamps of gemm.h (tools/gemm_stamps.py, profiles/) show where a k-step of a lone workgroup goes:
+// 543 cycles ISSUING its 8 global loads per wave (the CU's texture-address path moves ~60 B/clk of these 64-byte row
+// segments), 940 cycles LDS reads + 24 MFMAs, 640 cycles waiting for the loads and writing LDS, 190 at the barrier --
+// 2300 cycles for 768 cycles of MFMA.  The load issue and the MFMAs are serial inside every wave.  Here they are on
+// different waves:
+//   waves 4-7 (producers): LDS-DMA (global_load_lds_dwordx4) of 8 one-KiB pieces per k-tile each, 3 tiles ahead in a
+//                          4 x 32 KiB ring, counted s_waitcnt vmcnt so only the oldest tile is retired per step;
+//   waves 0-3 (consumers): ds_read_b128 fragments + v_mfma_f32_32x32x16_bf16 only (64 x 64 per wave), then the epilogue.
+// One raw s_barrier per k-tile joins both groups: "tile kt has landed" for the consumers, "tile kt-1 is consumed" for
+// the producers, which then refill that stage.  Same LDS image / swizzle / epilogue as gemm2.h.
+#pragma once
+#include "gemm2.h"
+
+template <int NSPLIT, int EPI>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm3_kernel(const GemmArgs p) {
+    constexpr int BM = 128, BN = 128, TM = 2, TN = 2, NST = 4;
+    constexpr int A_PLANE = BM * 64, B_PLANE = BN * 64, STAGE = NSPLIT * (A_PLANE + B_PLANE);
+    constexpr int P = STAGE / 1024 / 4;   // DMA pieces per producer wave per k-tile
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int nk = p.K >> 5;
+
+    if (wave >= 4) {
+        // ------------------------------------------------------------------ producers
+        const int pw = wave - 4;
+        const char* gsrc[P];
+#pragma unroll
+        for (int j = 0; j < P; j++) {
+            const int off = (pw * P + j) * 1024;
+            const bool isA = off < NSPLIT * A_PLANE;
+            const int rel = isA ? off : off - NSPLIT * A_PLANE;
+            const int plane_bytes = isA ? A_PLANE : B_PLANE;
+            const int pl = rel / plane_bytes;
+            const int row = (rel - pl * plane_bytes) / 64 + (lane >> 2);
+            const int chunk = (lane & 3) ^ ((row >> 2) & 3);
+            const __bf16* base = isA ? p.A[pl] + (size_t)(m0 + row) * p.lda : p.W[pl] + (size_t)(n0 + row) * p.ldw;
+            gsrc[j] = reinterpret_cast<const char*>(base + chunk * 8);
+        }
+        auto issue_tile = [&](int kt) {
+            char* dst = smem + (kt % NST) * STAGE + pw * (P * 1024);
+#pragma unroll
+            for (int j = 0; j < P; j++)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc[j] + (size_t)kt * 64),
+                                                 (__attribute__((address_space(3))) void*)(dst + j * 1024), 16, 0, 0);
+        };
+#pragma unroll
+        for (int t = 0; t < NST - 1; t++)
+            if (t < nk) issue_tile(t);
+        for (int kt = 0; kt < nk; kt++) {
+            const int newer = min(NST - 2, nk - 1 - kt);
+            if (newer >= 2) wait_vmcnt<2 * P>();
+            else if (newer == 1) wait_vmcnt<P>();
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            if (kt + NST - 1 < nk) issue_tile(kt + NST - 1);
+        }
+        __syncthreads();   // pairs with the workgroup barrier at the top of gemm_epilogue (consumers)
+        return;
+    }
+
+    // ---------------------------------------------------------------------- consumers
+    const int wm = wave >> 1, wn = wave & 1;
+    const int fr = lane & 31, fh = lane >> 5;
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int g = 0; g < 16; g++) acc[i][j][g] = 0.0f;
+
+    // Software-pipelined fragments: the LDS reads of the NEXT half k-step (16 k) are always issued before the 12 MFMAs of the
+    // current one, so with one consumer wave per SIMD the LDS latency hides behind 384 MFMA cycles.
+    bf16x8 fa[2][NSPLIT][TM], fb[2][NSPLIT][TN];
+    auto read_frags = [&](int buf, const char* st, int s) {
+        const int chunk = s * 2 + fh;
+#pragma unroll
+        for (int pl = 0; pl < NSPLIT; pl++) {
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+                fa[buf][pl][i] = *reinterpret_cast<const bf16x8*>(st + pl * A_PLANE + lds_off2(wm * 64 + i * 32 + fr, chunk));
+#pragma unroll
+            for (int j = 0; j < TN; j++)
+                fb[buf][pl][j] = *reinterpret_cast<const bf16x8*>(st + NSPLIT * A_PLANE + pl * B_PLANE + lds_off2(wn * 64 + j * 32 + fr, chunk));
+        }
+    };
+    auto mfma_frags = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int j = 0; j < TN; j++) {
+                if (NSPLIT == 2) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[buf][1][i], fb[buf][0][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[buf][0][i], fb[buf][1][j], acc[i][j], 0, 0, 0);
+                }
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[buf][0][i], fb[buf][0][j], acc[i][j], 0, 0, 0);
+            }
+    };
+    __builtin_amdgcn_s_barrier();                         // B_0: tile 0 landed
+    read_frags(0, smem, 0);
+    for (int kt = 0; kt < nk; kt++) {
+        const char* st = smem + (kt % NST) * STAGE;
+        read_frags(1, st, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_frags(0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 1 < nk) {
+            // every LDS read of tile kt has returned (they were issued 12 MFMAs ago): the producers may refill its stage
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                 // B_{kt+1}: tile kt+1 landed
+            read_frags(0, smem + ((kt + 1) % NST) * STAGE, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        mfma_frags(1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    gemm_epilogue<EPI, TM, TN>(p, acc, reinterpret_cast<float*>(smem) + wave * (TM * TN * 1024), m0 + wm * 64, n0 + wn * 64, n0, lane);
+}
+
+template <int NSPLIT, int EPI>
+static hipError_t launch_gemm3_t(const GemmArgs& a, int m_pad, int n_pad, hipStream_t st) {
+    constexpr int LDS = 4 * NSPLIT * (128 + 128) * 64 > 65536 ? 4 * NSPLIT * (128 + 128) * 64 : 65536;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm3_kernel<NSPLIT, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    dim3 grid(n_pad / 128, m_pad / 128);
+    hipLaunchKernelGGL((gemm3_kernel<NSPLIT, EPI>), grid, dim3(512), LDS, st, a);
+    return hipGetLastError();
+}
