@@ -65,6 +65,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--gemm-planes", type=int, default=2, help="2 = split-bf16 parity mode (default), 1 = plain bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batch", type=int, default=1, help="utterances per GPU per step (1 = BASELINE configs[1]; 8 = configs[2] per-GPU share)")
+    ap.add_argument("--vocoder", default="vocos", choices=["vocos", "bigvgan"], help="bigvgan = BASELINE configs[3]")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -84,6 +86,11 @@ def main():
     sd, vsd = synth.dit_state_dict(), synth.vocos_state_dict()
     model = F5HipModel(F5TTS_BASE, sd, gemm_planes=args.gemm_planes, device=dev)
     vocos = F5HipVocos(vsd, gemm_planes=args.gemm_planes, device=dev)
+    bigv = None
+    if args.vocoder == "bigvgan":
+        from tts_indic_server_f5_amd.vocoder import F5HipBigVGAN
+        bigv = F5HipBigVGAN(synth.bigvgan_state_dict(), gemm_planes=args.gemm_planes, device=dev)
+    B = args.batch
 
     # rank 0 owns the reference-audio latents; every rank has its own gen text + noise (distinct seeds)
     gc = torch.Generator().manual_seed(14)
@@ -91,15 +98,15 @@ def main():
     ids = synth.text_ids(N_REF_IDS, N_GEN_IDS, seed=synth.SEED_TEXT + rank)[0]
     ref_ids0 = synth.text_ids(N_REF_IDS, 0)[0].to(dev) if rank == 0 else None
     gen_ids = ids[N_REF_IDS:].to(dev)
-    y0 = synth.noise(N_TOTAL, rank)[None].to(dev)
+    y0 = torch.stack([synth.noise(N_TOTAL, rank * B + i) for i in range(B)]).to(dev)
 
     def one_step():
         cond, ref_ids = broadcast_ref_latents(cond0, ref_ids0, dev)
-        text = torch.cat([ref_ids, gen_ids])[None]
-        out, _ = model.sample(cond[None], text, N_TOTAL, steps=STEPS_NFE, cfg_strength=CFG, sway_sampling_coef=SWAY, y0=y0)
+        text = torch.cat([ref_ids, gen_ids])[None].expand(B, -1)
+        out, _ = model.sample(cond[None].expand(B, -1, -1), text, N_TOTAL, steps=STEPS_NFE, cfg_strength=CFG, sway_sampling_coef=SWAY, y0=y0)
         mel = out[:, N_REF:, :].permute(0, 2, 1)
-        wave = vocos.decode(mel)
-        return wave.squeeze().cpu()
+        wave = bigv(mel) if bigv is not None else vocos.decode(mel)
+        return wave.reshape(B, -1).cpu()
 
     def sync():
         torch.cuda.synchronize()
@@ -120,7 +127,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
     gen_frames = N_TOTAL - N_REF
-    value = gen_frames * world * args.steps / dt
+    value = gen_frames * B * world * args.steps / dt
     audio_s = wave.numel() / 24000.0
 
     result = None
@@ -139,17 +146,17 @@ def main():
         L.f5hip_set_profiling(0)
         g = prof["gemm"]
         # the profiled pass also ran the hoisted / Vocos GEMMs; their share of launches and time is < 2 %
-        gemm_flops = gemm_algorithmic_flops()
+        gemm_flops = gemm_algorithmic_flops() * B
         achieved = gemm_flops / (g["total_ms"] * 1e-3) / 1e12 if g["total_ms"] > 0 else 0.0
         att = prof["attn"]
-        attn_tf = attn_algorithmic_flops() / (att["total_ms"] * 1e-3) / 1e12 if att["total_ms"] > 0 else 0.0
+        attn_tf = attn_algorithmic_flops() * B / (att["total_ms"] * 1e-3) / 1e12 if att["total_ms"] > 0 else 0.0
         result = {
             "metric": "mel-frames/sec + RTF, F5-TTS-Base 32-NFE, 10s utterance", "value": round(value, 1),
             "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "rtf": round(dt / args.steps / audio_s, 6),
-            "config": {"workload": "F5-TTS-Base, 32 NFE + CFG=2.0 + sway -1, Vocos, one 10 s utterance (N=1404, 936 generated frames) per GPU per step",
+            "config": {"workload": f"F5-TTS-Base, 32 NFE + CFG=2.0 + sway -1, {'BigVGAN' if bigv is not None else 'Vocos'}, {B} x 10 s utterance (N=1404, 936 generated frames) per GPU per step",
                        "gemm_mode": "bf16x3 split (hi*hi+hi*lo+lo*hi, fp32 acc) - parity mode" if args.gemm_planes == 2 else "plain bf16 (misses the 1e-3 mel bound)",
                        "attention": "bf16 MFMA, fp32 softmax", "parallelism": f"utterance-sharded x{world}, RCCL broadcast of ref latents"},
             "roofline": {"bound": "mfma", "kernel": "gemm_kernel (all instantiations)", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS,
@@ -159,7 +166,7 @@ def main():
                          "attn_tflops": round(attn_tf, 1), "attn_frac": round(attn_tf / PEAK_BF16_TFLOPS, 4)},
             "kernel_ms": prof,
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and B == 1 and bigv is None:
             n_threads = min(len(os.sched_getaffinity(0)), 32)
             result["cpu_baseline"] = cpu_baseline(sd, vsd, cond0.cpu()[None], torch.cat([ref_ids0, gen_ids]).cpu()[None], y0.cpu(), n_threads)
         print(json.dumps(result), flush=True)
