@@ -146,3 +146,30 @@ def test_unett_small_forward_vs_reference_fixture(golden_dir):
     ref = g["out_cond"]
     e = _report("unett small forward", out, ref)
     assert e < 1e-3 * max(1.0, ref.pow(2).mean().sqrt().item())   # un-gated residual stream: output rms is > 1
+
+
+def test_ragged_batch_is_per_item_batch1(tiny_model):
+    """sample() on a ragged batch == each item sampled alone with the reference's batch-1 semantics (pad-free sharding,
+    SURVEY Appendix B4), incl. edit_mask, cfg = 0 and a workspace that grows / shrinks between calls."""
+    sd = synth.dit_state_dict(**TINY)
+    cfg = O.DiTConfig(**TINY)
+    g = torch.Generator().manual_seed(41)
+    cond = torch.randn(3, 20, 100, generator=g)
+    text = torch.randint(0, 40, (3, 26), generator=g)
+    text[1, 18:] = -1
+    text[2, 7:] = -1
+    durs = torch.tensor([70, 300, 41])
+    y0 = [torch.randn(int(d), 100, generator=g) for d in durs]
+    out, _ = tiny_model.sample(cond, text, durs, steps=6, cfg_strength=2.0, sway_sampling_coef=-1.0, y0=y0)
+    for i in range(3):
+        ref, _ = O.cfm_sample(sd, cfg, cond[i:i + 1], text[i:i + 1], int(durs[i]), steps=6, cfg_strength=2.0,
+                              sway_sampling_coef=-1.0, y0=y0[i][None], keep_trajectory=False)
+        n = ref.shape[1]
+        assert _report(f"ragged item {i} (n={n})", out[i, :n], ref[0]) < 1e-3
+        assert (out[i, n:] == 0).all()
+    em = torch.ones(1, 26, dtype=torch.bool)   # same shape as cond_mask = lens_to_mask(max(text_len, cond_len)) (cfm.py:129-131)
+    em[0, 5:12] = False
+    ref, _ = O.cfm_sample(sd, cfg, cond[:1], text[:1], 64, steps=5, cfg_strength=0.0, sway_sampling_coef=None, y0=y0[0][None, :64],
+                          edit_mask=em, keep_trajectory=False)
+    got, _ = tiny_model.sample(cond[:1], text[:1], 64, steps=5, cfg_strength=0.0, sway_sampling_coef=None, y0=y0[0][None, :64], edit_mask=em)
+    assert _report("edit_mask cfg0", got, ref) < 1e-3

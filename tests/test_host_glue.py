@@ -73,3 +73,19 @@ def test_load_wav_roundtrip(tmp_path):
         f.setnchannels(1); f.setsampwidth(2); f.setframerate(24000); f.writeframes(x.tobytes())
     a, sr = infer.load_wav(p)
     assert sr == 24000 and a.shape == (1, 2400) and abs(float(a[0, 10]) - x[10] / 32768.0) < 1e-7
+
+
+def test_resample_known_answers():
+    """torchaudio-style sinc resampler (third-party leaf, parity unpinned): length rule, tone preservation, identity."""
+    import math
+    sr = 16000
+    n = 16000
+    t = torch.arange(n) / sr
+    x = 0.5 * torch.sin(2 * math.pi * 440.0 * t)[None]
+    y = infer.resample_sinc_hann(x, sr, 24000)
+    assert y.shape == (1, math.ceil(24000 * n / sr))
+    ref = 0.5 * torch.sin(2 * math.pi * 440.0 * torch.arange(y.shape[1]) / 24000.0)
+    assert (y[0, 200:-200] - ref[200:-200]).abs().max() < 2e-3        # band-limited tone survives, away from the edges
+    assert infer.resample_sinc_hann(x, 24000, 24000) is x
+    z = infer.resample_sinc_hann(torch.randn(2, 44100), 44100, 24000)
+    assert z.shape == (2, 24000) and torch.isfinite(z).all()

@@ -6,7 +6,8 @@ cross-fade ramps), running the sampler and vocoder on the HIP objects (`F5HipMod
 Host-side differences, all explicit:
   * reference audio is read with the stdlib `wave` module (16-bit PCM WAV) or passed as a `(tensor, sr)` pair:
     torchaudio is not part of this image;
-  * resampling to 24 kHz is not implemented yet (SURVEY §8(f) rank 2): a non-24 kHz reference raises;
+  * resampling to 24 kHz restates torchaudio.transforms.Resample (sinc interpolation, Hann window, width 6, rolloff
+    0.99; third-party leaf, parity unpinned) on the host, like the reference does before `.to(device)`;
   * `convert_char_to_pinyin` (jieba + pypinyin) is replaced by `text_to_tokens`, which reproduces the reference's
     behaviour for text without CJK characters (per-character tokens, the same punctuation translation table)
     and rejects CJK input instead of silently mis-tokenising it.
@@ -69,6 +70,35 @@ def text_to_tokens(text_list):
     return out
 
 
+def resample_sinc_hann(wave: torch.Tensor, orig_freq: int, new_freq: int, lowpass_filter_width: int = 6,
+                       rolloff: float = 0.99) -> torch.Tensor:
+    """torchaudio.transforms.Resample(orig_freq, new_freq) (call site F/infer/utils_infer.py:430-432), default
+    "sinc_interp_hann" method of torchaudio 2.6: polyphase windowed-sinc kernel applied as a strided conv1d.
+    wave [channels, n] -> [channels, ceil(n * new / orig)]."""
+    import math
+    if orig_freq == new_freq:
+        return wave
+    g = math.gcd(int(orig_freq), int(new_freq))
+    of, nf = int(orig_freq) // g, int(new_freq) // g
+    base_freq = min(of, nf) * rolloff
+    width = math.ceil(lowpass_filter_width * of / base_freq)
+    idx = torch.arange(-width, width + of, dtype=torch.float64)[None, None] / of
+    t = torch.arange(0, -nf, -1, dtype=torch.float64)[:, None, None] / nf + idx
+    t = (t * base_freq).clamp(-lowpass_filter_width, lowpass_filter_width)
+    window = torch.cos(t * math.pi / lowpass_filter_width / 2) ** 2
+    t = t * math.pi
+    kernels = torch.where(t == 0, torch.ones_like(t), t.sin() / t) * window * (base_freq / of)
+    kernels = kernels.to(torch.float32)
+    shape = wave.shape
+    w = wave.reshape(-1, shape[-1]).to(torch.float32)
+    length = w.shape[-1]
+    w = torch.nn.functional.pad(w, (width, width + of))
+    out = torch.nn.functional.conv1d(w[:, None], kernels, stride=of)
+    out = out.transpose(1, 2).reshape(w.shape[0], -1)
+    target = math.ceil(nf * length / of)
+    return out[..., :target].reshape(*shape[:-1], target)
+
+
 def load_wav(path):
     """16-bit PCM WAV -> (float32 tensor [channels, samples] in [-1, 1), sample_rate) like torchaudio.load."""
     with _wave.open(path, "rb") as f:
@@ -105,7 +135,7 @@ def infer_batch_process(ref_audio, ref_text, gen_text_batches, model_obj, vocode
     if rms < target_rms:
         audio = audio * target_rms / rms
     if sr != target_sample_rate:
-        raise NotImplementedError(f"reference audio must be {target_sample_rate} Hz (resampling is a next-row item)")
+        audio = resample_sinc_hann(audio, sr, target_sample_rate)
     if device is not None:
         audio = audio.to(device)
 
