@@ -69,14 +69,23 @@ def main():
     ap.add_argument("--vocoder", default="vocos", choices=["vocos", "bigvgan"], help="bigvgan = BASELINE configs[3]")
     args = ap.parse_args()
 
+    if os.environ.get("F5HIP_BENCH_WATCHDOG"):          # dump every thread's stack and exit if the run stalls
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["F5HIP_BENCH_WATCHDOG"]), exit=True)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # one process per GPU; F5HIP_DIST_BACKEND=gloo + several ranks on one card is only for rehearsing the N > 1 path on a 1-GPU box
+    backend = os.environ.get("F5HIP_DIST_BACKEND", "nccl")
+    dev_index = local_rank % max(1, torch.cuda.device_count())
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device(f"cuda:{local_rank}")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{dev_index}"))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device(f"cuda:{dev_index}")
 
     from tts_indic_server_f5_amd import _lib, synth
     from tts_indic_server_f5_amd.model import F5TTS_BASE, F5HipModel
@@ -100,8 +109,9 @@ def main():
     gen_ids = ids[N_REF_IDS:].to(dev)
     y0 = torch.stack([synth.noise(N_TOTAL, rank * B + i) for i in range(B)]).to(dev)
 
-    def one_step():
-        cond, ref_ids = broadcast_ref_latents(cond0, ref_ids0, dev)
+    def one_step(exchange=True):
+        # exchange=False (rank 0's untimed profiling pass) must not enter a collective the other ranks never join
+        cond, ref_ids = broadcast_ref_latents(cond0, ref_ids0, dev) if exchange else (cond0, ref_ids0)
         text = torch.cat([ref_ids, gen_ids])[None].expand(B, -1)
         out, _ = model.sample(cond[None].expand(B, -1, -1), text, N_TOTAL, steps=STEPS_NFE, cfg_strength=CFG, sway_sampling_coef=SWAY, y0=y0)
         mel = out[:, N_REF:, :].permute(0, 2, 1)
@@ -135,7 +145,7 @@ def main():
         # per-kernel-class durations: one more pass with HIP events around every launch on the launch stream
         L = _lib.lib()
         L.f5hip_set_profiling(1)
-        one_step()
+        one_step(exchange=False)
         torch.cuda.synchronize()
         import ctypes as C
         prof = {}
