@@ -26,7 +26,7 @@ extern "C" int f5hip_debug_gemm_stamps(int32_t M, int32_t N, int32_t K, int32_t 
     a.act = ACT_GELU_TANH; a.out_hi = O.hi; a.out_lo = O.lo; a.ldob = N; a.stamps = dst;
     if (bx < 0) { bx = -bx - 1; a.act = ACT_NONE; a.out_hi = nullptr; a.out_lo = nullptr; hipMalloc(&a.out_f32, no * 4); a.ldo = N; a.res = a.out_f32; a.ldres = N; } a.stamp_bx = bx; a.stamp_by = by;
     hipError_t e = hipSuccess;
-    for (int it = 0; it < 3; it++) e = bn == 128 ? launch_gemm_t<2, 128, false, EPI_GENERIC, 3>(a, M, N, 0) : launch_gemm_t<2, 64, false, EPI_GENERIC, 3>(a, M, N, 0);
+    for (int it = 0; it < 3; it++) e = bn == 3 ? launch_gemm3_t<2, EPI_GENERIC, 3>(a, M, N, 0) : bn == 128 ? launch_gemm_t<2, 128, false, EPI_GENERIC, 3>(a, M, N, 0) : launch_gemm_t<2, 64, false, EPI_GENERIC, 3>(a, M, N, 0);
     hipDeviceSynchronize();
     hipMemcpy(out, dst, 88, hipMemcpyDeviceToHost);
     for (void* p : {(void*)fa, (void*)fw, (void*)A.hi, (void*)A.lo, (void*)O.hi, (void*)O.lo, (void*)W.hi, (void*)W.lo, (void*)dst}) hipFree(p);
@@ -61,6 +61,8 @@ extern "C" int f5hip_debug_gemm_bench(int32_t M, int32_t N, int32_t K, int32_t p
         if (it == 0) hipEventRecord(e0, 0);
         if (variant == 20) e = planes == 2 ? launch_gemm2_t<2, 128, 128, EPI_GENERIC>(a, M, N, 0) : launch_gemm2_t<1, 128, 128, EPI_GENERIC>(a, M, N, 0);
         else if (variant == 30) e = planes == 2 ? launch_gemm3_t<2, EPI_GENERIC>(a, M, N, 0) : launch_gemm3_t<1, EPI_GENERIC>(a, M, N, 0);
+        else if (variant == 31) e = launch_gemm3_t<2, EPI_GENERIC, 1>(a, M, N, 0);
+        else if (variant == 32) e = launch_gemm3_t<2, EPI_GENERIC, 2>(a, M, N, 0);
         else if (variant == 21) e = planes == 2 ? launch_gemm2_t<2, 256, 128, EPI_GENERIC>(a, M, N, 0) : launch_gemm2_t<1, 256, 128, EPI_GENERIC>(a, M, N, 0);
         else if (planes == 2 && bn == 128) {
             if (variant == 0) e = launch_gemm_t<2, 128, false, EPI_GENERIC, 0>(a, M, N, 0);

@@ -13,7 +13,8 @@
 #pragma once
 #include "gemm2.h"
 
-template <int NSPLIT, int EPI>
+// ABL (diagnostics only): 0 = normal, 1 = producers issue no DMA (consumers read whatever is in LDS), 2 = consumers skip the MFMAs
+template <int NSPLIT, int EPI, int ABL = 0>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm3_kernel(const GemmArgs p) {
     constexpr int BM = 128, BN = 128, TM = 2, TN = 2, NST = 4;
     constexpr int A_PLANE = BM * 64, B_PLANE = BN * 64, STAGE = NSPLIT * (A_PLANE + B_PLANE);
@@ -50,14 +51,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         };
 #pragma unroll
         for (int t = 0; t < NST - 1; t++)
-            if (t < nk) issue_tile(t);
+            if (t < nk && ABL != 1) issue_tile(t);
         for (int kt = 0; kt < nk; kt++) {
             const int newer = min(NST - 2, nk - 1 - kt);
             if (newer >= 2) wait_vmcnt<2 * P>();
             else if (newer == 1) wait_vmcnt<P>();
             else wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
-            if (kt + NST - 1 < nk) issue_tile(kt + NST - 1);
+            if (kt + NST - 1 < nk && ABL != 1) issue_tile(kt + NST - 1);
         }
         __syncthreads();   // pairs with the workgroup barrier at the top of gemm_epilogue (consumers)
         return;
@@ -90,6 +91,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
     };
     auto mfma_frags = [&](int buf) {
+        if constexpr (ABL == 2) {
+            asm volatile("" :: "v"(fa[buf][0][0]), "v"(fb[buf][0][0]), "v"(fa[buf][NSPLIT - 1][TM - 1]), "v"(fb[buf][NSPLIT - 1][TN - 1]));
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < TM; i++)
 #pragma unroll
@@ -101,7 +106,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[buf][0][i], fb[buf][0][j], acc[i][j], 0, 0, 0);
             }
     };
+    unsigned long long ts[4] = {0, 0, 0, 0};
+#define G3_STAMP(I) if constexpr (ABL == 3) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts[I])::"memory"); __builtin_amdgcn_sched_barrier(0); }
+    G3_STAMP(0);
     __builtin_amdgcn_s_barrier();                         // B_0: tile 0 landed
+    G3_STAMP(1);
     read_frags(0, smem, 0);
     for (int kt = 0; kt < nk; kt++) {
         const char* st = smem + (kt % NST) * STAGE;
@@ -119,19 +128,29 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         mfma_frags(1);
         __builtin_amdgcn_sched_barrier(0);
     }
-    gemm_epilogue<EPI, TM, TN>(p, acc, reinterpret_cast<float*>(smem) + wave * (TM * TN * 1024), m0 + wm * 64, n0 + wn * 64, n0, lane);
+    G3_STAMP(2);
+    unsigned long long epi_dbg[4] = {0, 0, 0, 0};
+    gemm_epilogue<EPI, TM, TN>(p, acc, reinterpret_cast<float*>(smem) + wave * (TM * TN * 1024), m0 + wm * 64, n0 + wn * 64, n0, lane, ABL == 3 ? epi_dbg : nullptr);
+    G3_STAMP(3);
+#undef G3_STAMP
+    if constexpr (ABL == 3) {
+        if (p.stamps && blockIdx.x == p.stamp_bx && blockIdx.y == p.stamp_by && tid == 0) {
+            p.stamps[0] = ts[1] - ts[0]; p.stamps[1] = ts[2] - ts[1]; p.stamps[2] = ts[3] - ts[2]; p.stamps[3] = ts[0];
+            for (int i = 0; i < 4; i++) p.stamps[7 + i] = epi_dbg[i];
+        }
+    }
 }
 
-template <int NSPLIT, int EPI>
+template <int NSPLIT, int EPI, int ABL = 0>
 static hipError_t launch_gemm3_t(const GemmArgs& a, int m_pad, int n_pad, hipStream_t st) {
     constexpr int LDS = 4 * NSPLIT * (128 + 128) * 64 > 65536 ? 4 * NSPLIT * (128 + 128) * 64 : 65536;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm3_kernel<NSPLIT, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm3_kernel<NSPLIT, EPI, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     dim3 grid(n_pad / 128, m_pad / 128);
-    hipLaunchKernelGGL((gemm3_kernel<NSPLIT, EPI>), grid, dim3(512), LDS, st, a);
+    hipLaunchKernelGGL((gemm3_kernel<NSPLIT, EPI, ABL>), grid, dim3(512), LDS, st, a);
     return hipGetLastError();
 }

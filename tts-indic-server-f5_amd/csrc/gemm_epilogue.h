@@ -53,14 +53,17 @@ struct GemmArgs {
 // one 32 x WN slice staged in `stg` (fp32, row stride WN): generic epilogue, lane owns 4 columns of 32 / RPP rows.
 // RES / OUTF / OUTS (residual present, fp32 output, split-bf16 output) are compile-time so the hot variants carry no
 // per-element pointer tests; row pointers advance incrementally (one 64-bit add per row group instead of a 64-bit multiply).
-template <int ACT, int WN, int ROWS, bool RES, bool OUTF, bool OUTS>
+// GUARD = false is the interior fast path (whole wave tile inside M x N, no column groups, no row_keep): straight-line code, so
+// the compiler counts vmcnt exactly -- all residual loads in flight, stores never waited on.  With per-row-group exec
+// branches (GUARD = true) it falls back to s_waitcnt vmcnt(0) per group, which serialises every store's latency.
+template <int ACT, int WN, int ROWS, bool RES, bool OUTF, bool OUTS, bool GUARD>
 F5_DEVICE void epi_generic_rows_t(const GemmArgs& p, const float* stg, int m_base, int n_base, int lane) {
     constexpr int LPR = WN / 4, RPP = 64 / LPR, NQ = ROWS / RPP;
     const int c4 = (lane % LPR) * 4, r0 = lane / LPR;
     const int n = n_base + c4;   // column in the (possibly group-padded) weight layout
     int no = n;                  // column in the output / residual / multiplier
-    bool nok = n < ((p.N + 3) & ~3);
-    if (p.group_w) {
+    bool nok = GUARD ? n < ((p.N + 3) & ~3) : true;
+    if (GUARD && p.group_w) {
         nok = nok && (n & 63) < p.group_w;
         no = (n >> 6) * p.group_w + (n & 63);
     }
@@ -76,13 +79,13 @@ F5_DEVICE void epi_generic_rows_t(const GemmArgs& p, const float* stg, int m_bas
         rs[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
         keep[q] = 1;
         if (RES) {
-            if (nok && mrow + q * RPP < p.M) rs[q] = *reinterpret_cast<const f32x4*>(rp + (size_t)q * RPP * p.ldres);
+            if (!GUARD || (nok && mrow + q * RPP < p.M)) rs[q] = *reinterpret_cast<const f32x4*>(rp + (size_t)q * RPP * p.ldres);
         }
-        if (p.row_keep) keep[q] = p.row_keep[mrow + q * RPP];
+        if (GUARD && p.row_keep) keep[q] = p.row_keep[mrow + q * RPP];
     }
     float* of = OUTF ? p.out_f32 + (size_t)mrow * p.ldo + no : nullptr;
     __bf16* oh = OUTS ? p.out_hi + (size_t)mrow * p.ldob + no : nullptr;
-    __bf16* ol = OUTS && p.out_lo ? p.out_lo + (size_t)mrow * p.ldob + no : nullptr;
+    __bf16* ol = OUTS && (!GUARD || p.out_lo) ? p.out_lo + (size_t)mrow * p.ldob + no : nullptr;
     const size_t sf = (size_t)RPP * p.ldo, sb = (size_t)RPP * p.ldob;
 #pragma unroll
     for (int q = 0; q < NQ; q++) {
@@ -91,78 +94,101 @@ F5_DEVICE void epi_generic_rows_t(const GemmArgs& p, const float* stg, int m_bas
 #pragma unroll
             for (int e = 0; e < 4; e++) v[e] = apply_act(v[e], ACT);
         }
-        if (!keep[q]) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (GUARD && !keep[q]) v = (f32x4){0.f, 0.f, 0.f, 0.f};
         v = v * mv + rs[q];
-        if (nok && mrow + q * RPP < p.M) {
+        if (!GUARD || (nok && mrow + q * RPP < p.M)) {
             if (OUTF) *reinterpret_cast<f32x4*>(of + q * sf) = v;
             if (OUTS) {
                 bf16x4 hi, lo;
                 const float vv[4] = {v[0], v[1], v[2], v[3]};
                 split_bf16x4(vv, hi, lo);
                 *reinterpret_cast<bf16x4*>(oh + q * sb) = hi;
-                if (ol) *reinterpret_cast<bf16x4*>(ol + q * sb) = lo;
+                if (!GUARD || ol) *reinterpret_cast<bf16x4*>(ol + q * sb) = lo;
             }
         }
     }
 }
 
-template <int ACT, int WN, int ROWS>
-F5_DEVICE void epi_generic_rows(const GemmArgs& p, const float* stg, int m_base, int n_base, int lane) {
+template <int ACT, int WN, int ROWS, bool GUARD>
+F5_DEVICE void epi_generic_rows_g(const GemmArgs& p, const float* stg, int m_base, int n_base, int lane) {
     const bool res = p.res != nullptr, outf = p.out_f32 != nullptr, outs = p.out_hi != nullptr;
     if (ACT == ACT_NONE) {   // residual / plain projections: every output combination occurs
         if (res) {
-            if (outf && outs) epi_generic_rows_t<ACT, WN, ROWS, true, true, true>(p, stg, m_base, n_base, lane);
-            else if (outf) epi_generic_rows_t<ACT, WN, ROWS, true, true, false>(p, stg, m_base, n_base, lane);
-            else epi_generic_rows_t<ACT, WN, ROWS, true, false, true>(p, stg, m_base, n_base, lane);
+            if (outf && outs) epi_generic_rows_t<ACT, WN, ROWS, true, true, true, GUARD>(p, stg, m_base, n_base, lane);
+            else if (outf) epi_generic_rows_t<ACT, WN, ROWS, true, true, false, GUARD>(p, stg, m_base, n_base, lane);
+            else epi_generic_rows_t<ACT, WN, ROWS, true, false, true, GUARD>(p, stg, m_base, n_base, lane);
         } else {
-            if (outf && outs) epi_generic_rows_t<ACT, WN, ROWS, false, true, true>(p, stg, m_base, n_base, lane);
-            else if (outf) epi_generic_rows_t<ACT, WN, ROWS, false, true, false>(p, stg, m_base, n_base, lane);
-            else epi_generic_rows_t<ACT, WN, ROWS, false, false, true>(p, stg, m_base, n_base, lane);
+            if (outf && outs) epi_generic_rows_t<ACT, WN, ROWS, false, true, true, GUARD>(p, stg, m_base, n_base, lane);
+            else if (outf) epi_generic_rows_t<ACT, WN, ROWS, false, true, false, GUARD>(p, stg, m_base, n_base, lane);
+            else epi_generic_rows_t<ACT, WN, ROWS, false, false, true, GUARD>(p, stg, m_base, n_base, lane);
         }
     } else {                 // activations: (no residual -> split or fp32) and (residual -> fp32) are the combinations in use
-        if (res) epi_generic_rows_t<ACT, WN, ROWS, true, true, false>(p, stg, m_base, n_base, lane);
-        else if (outs && !outf) epi_generic_rows_t<ACT, WN, ROWS, false, false, true>(p, stg, m_base, n_base, lane);
-        else if (outf && !outs) epi_generic_rows_t<ACT, WN, ROWS, false, true, false>(p, stg, m_base, n_base, lane);
-        else epi_generic_rows_t<ACT, WN, ROWS, false, true, true>(p, stg, m_base, n_base, lane);
+        if (res) epi_generic_rows_t<ACT, WN, ROWS, true, true, false, GUARD>(p, stg, m_base, n_base, lane);
+        else if (outs && !outf) epi_generic_rows_t<ACT, WN, ROWS, false, false, true, GUARD>(p, stg, m_base, n_base, lane);
+        else if (outf && !outs) epi_generic_rows_t<ACT, WN, ROWS, false, true, false, GUARD>(p, stg, m_base, n_base, lane);
+        else epi_generic_rows_t<ACT, WN, ROWS, false, true, true, GUARD>(p, stg, m_base, n_base, lane);
     }
+}
+
+template <int ACT, int WN, int ROWS>
+F5_DEVICE void epi_generic_rows(const GemmArgs& p, const float* stg, int m_base, int n_base, int lane) {
+    // wave-uniform: interior tile with both split planes (or none) and no per-row / per-group special cases
+    const bool interior = m_base + ROWS <= p.M && n_base + WN <= p.N && !p.group_w && !p.row_keep && (!p.out_hi || p.out_lo);
+    if (interior) epi_generic_rows_g<ACT, WN, ROWS, false>(p, stg, m_base, n_base, lane);
+    else epi_generic_rows_g<ACT, WN, ROWS, true>(p, stg, m_base, n_base, lane);
 }
 
 // Q / K blocks of the fused QKV projection: bias, rotary embedding on head 0 (x-transformers interleaved pairs, applied
 // before the head split: F/model/modules.py:414-419), q * 1/8 (softmax scale, exact in bf16), bf16 row-major [M][2 D]
-template <int WN, int ROWS>
-F5_DEVICE void epi_qk_rows(const GemmArgs& p, const float* stg, int m_base, int n_base, int lane) {
+template <int WN, int ROWS, bool ROT, bool GUARD>
+F5_DEVICE void epi_qk_rows_t(const GemmArgs& p, const float* stg, int m_base, int n_base, int lane) {
     constexpr int LPR = WN / 4, RPP = 64 / LPR, NQ = ROWS / RPP;
     const int c4 = (lane % LPR) * 4, r0 = lane / LPR;
     const int n = n_base + c4;
     const int D = p.D;
     const int which = n_base / D;    // 0 q, 1 k (uniform per wave: D % 64 == 0)
     const int nd = n - which * D;
-    const bool rot = nd < 64;        // head 0 only
     const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n);
-    int pos[NQ];
-#pragma unroll
-    for (int q = 0; q < NQ; q++) pos[q] = rot ? p.row_pos[m_base + q * RPP + r0] : 0;
     float2 cs[NQ], sn[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; q++) {
         cs[q] = make_float2(1.f, 1.f);
         sn[q] = make_float2(0.f, 0.f);
-        if (rot) {
-            cs[q] = *reinterpret_cast<const float2*>(p.rope_cos + pos[q] * 32 + (nd >> 1));
-            sn[q] = *reinterpret_cast<const float2*>(p.rope_sin + pos[q] * 32 + (nd >> 1));
+        if (ROT) {
+            const int pos = p.row_pos[m_base + q * RPP + r0];
+            cs[q] = *reinterpret_cast<const float2*>(p.rope_cos + pos * 32 + (nd >> 1));
+            sn[q] = *reinterpret_cast<const float2*>(p.rope_sin + pos * 32 + (nd >> 1));
         }
     }
     const float qs = which == 0 ? 0.125f : 1.0f;
+    __bf16* op = p.qk + (size_t)(m_base + r0) * (2 * D) + which * D + nd;
 #pragma unroll
     for (int q = 0; q < NQ; q++) {
-        const int m = m_base + q * RPP + r0;
         const f32x4 v = *reinterpret_cast<const f32x4*>(stg + (q * RPP + r0) * WN + c4) + bv;
         bf16x4 o;
-        o[0] = (__bf16)((v[0] * cs[q].x - v[1] * sn[q].x) * qs);
-        o[1] = (__bf16)((v[1] * cs[q].x + v[0] * sn[q].x) * qs);
-        o[2] = (__bf16)((v[2] * cs[q].y - v[3] * sn[q].y) * qs);
-        o[3] = (__bf16)((v[3] * cs[q].y + v[2] * sn[q].y) * qs);
-        if (m < p.M) *reinterpret_cast<bf16x4*>(p.qk + (size_t)m * (2 * D) + which * D + nd) = o;
+        if (ROT) {
+            o[0] = (__bf16)((v[0] * cs[q].x - v[1] * sn[q].x) * qs);
+            o[1] = (__bf16)((v[1] * cs[q].x + v[0] * sn[q].x) * qs);
+            o[2] = (__bf16)((v[2] * cs[q].y - v[3] * sn[q].y) * qs);
+            o[3] = (__bf16)((v[3] * cs[q].y + v[2] * sn[q].y) * qs);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; e++) o[e] = (__bf16)(v[e] * qs);
+        }
+        if (!GUARD || m_base + q * RPP + r0 < p.M) *reinterpret_cast<bf16x4*>(op + (size_t)q * RPP * (2 * D)) = o;
+    }
+}
+
+template <int WN, int ROWS>
+F5_DEVICE void epi_qk_rows(const GemmArgs& p, const float* stg, int m_base, int n_base, int lane) {
+    const int which = n_base / p.D;
+    const bool rot = n_base - which * p.D < 64;   // head 0 only (wave-uniform)
+    if (m_base + ROWS <= p.M) {
+        if (rot) epi_qk_rows_t<WN, ROWS, true, false>(p, stg, m_base, n_base, lane);
+        else epi_qk_rows_t<WN, ROWS, false, false>(p, stg, m_base, n_base, lane);
+    } else {
+        if (rot) epi_qk_rows_t<WN, ROWS, true, true>(p, stg, m_base, n_base, lane);
+        else epi_qk_rows_t<WN, ROWS, false, true>(p, stg, m_base, n_base, lane);
     }
 }
 
