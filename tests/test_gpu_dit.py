@@ -30,10 +30,14 @@ def _report(tag, got, ref):
     return d.pow(2).mean().sqrt().item()
 
 
-@pytest.fixture(scope="module")
-def tiny_model():
+# every DiT parity test runs in both parity modes of the library: 2 = bf16x3 everywhere, 3 = fp16 block GEMMs + bf16x3 state GEMMs
+_MODE_PARAMS = dict(params=[2, 3], ids=["bf16x3", "mixed_f16"])
+
+
+@pytest.fixture(scope="module", **_MODE_PARAMS)
+def tiny_model(request):
     from tts_indic_server_f5_amd.model import DiTArch, F5HipModel
-    return F5HipModel(DiTArch(**TINY), synth.dit_state_dict(**TINY))
+    return F5HipModel(DiTArch(**TINY), synth.dit_state_dict(**TINY), gemm_planes=request.param)
 
 
 def test_tiny_taps_vs_reference_fixture(golden_dir, tiny_model):
@@ -90,10 +94,10 @@ def test_small_forward_vs_reference_fixture(golden_dir):
     assert e < 5e-2   # fast mode: documented to miss the 1e-3 bound
 
 
-@pytest.fixture(scope="module")
-def base_model():
+@pytest.fixture(scope="module", **_MODE_PARAMS)
+def base_model(request):
     from tts_indic_server_f5_amd.model import F5TTS_BASE, F5HipModel
-    return F5HipModel(F5TTS_BASE, synth.dit_state_dict())
+    return F5HipModel(F5TTS_BASE, synth.dit_state_dict(), gemm_planes=request.param)
 
 
 def test_base_forward_digest(golden_dir, base_model):

@@ -19,6 +19,7 @@ struct AttnArgs {
     const int* seq_kvlen;
     __bf16* out_hi;     // [M_pad][D]
     __bf16* out_lo;     // may be null
+    int f16_out;        // 1: out_hi receives one fp16 plane (A operand of the fp16 out-projection GEMM)
 };
 
 F5_DEVICE int lds_off128(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
@@ -159,8 +160,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 float ov[4];
 #pragma unroll
                 for (int e = 0; e < 4; e++) ov[e] = oacc[dt][a * 4 + e] * inv;
-                split_bf16x4(ov, hi4, lo4);
                 const int d = dt * 32 + 8 * a + 4 * fh;
+                if (p.f16_out) {
+                    store_f16x4(p.out_hi + obase + d, ov);
+                    continue;
+                }
+                split_bf16x4(ov, hi4, lo4);
                 *reinterpret_cast<bf16x4*>(p.out_hi + obase + d) = hi4;
                 if (p.out_lo) *reinterpret_cast<bf16x4*>(p.out_lo + obase + d) = lo4;
             }

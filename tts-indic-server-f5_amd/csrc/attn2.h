@@ -155,8 +155,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 float ov[4];
 #pragma unroll
                 for (int e = 0; e < 4; e++) ov[e] = oacc[dt][a * 4 + e] * inv;
-                split_bf16x4(ov, hi4, lo4);
                 const int d = dt * 32 + 8 * a + 4 * fh;
+                if (p.f16_out) {
+                    store_f16x4(p.out_hi + obase + d, ov);
+                    continue;
+                }
+                split_bf16x4(ov, hi4, lo4);
                 *reinterpret_cast<bf16x4*>(p.out_hi + obase + d) = hi4;
                 if (p.out_lo) *reinterpret_cast<bf16x4*>(p.out_lo + obase + d) = lo4;
             }

@@ -9,6 +9,8 @@ typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 
 #define F5_DEVICE __device__ __forceinline__
 
@@ -26,6 +28,21 @@ F5_DEVICE void split_bf16x4(const float* y, bf16x4& hi, bf16x4& lo) {
         hi[e] = h;
         lo[e] = l;
     }
+}
+
+// fp32 x 4 -> fp16 x 4 (round to nearest even), stored through a 2-byte-element pointer shared with the bf16 planes
+F5_DEVICE void store_f16x4(__bf16* dst, const float* y) {
+    f16x4 h;
+#pragma unroll
+    for (int e = 0; e < 4; e++) h[e] = (_Float16)y[e];
+    *reinterpret_cast<f16x4*>(dst) = h;
+}
+
+// one 32 x 32 x 16 MFMA on 16-byte fragments: bf16 operands, or (F16) the same bits read as fp16
+template <bool F16>
+F5_DEVICE f32x16 mfma_32x32x16(bf16x8 a, bf16x8 b, f32x16 c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
 // Activations on the hardware transcendental units (v_exp_f32 / v_rcp_f32 / v_log_f32, ~1 ulp each): the libm forms

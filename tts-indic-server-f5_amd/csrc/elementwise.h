@@ -17,6 +17,7 @@ struct LnArgs {
     const float* dw_w; const float* dw_b; const int* row_seq_start; const int* row_seq_end;
     __bf16* out_hi; __bf16* out_lo; int ldo;
     float* out_f32; int ldof;
+    int f16_out;   // 1: out_hi receives one fp16 plane (input of a PREC_F16 GEMM), out_lo unused
     int rms;   // 1: x-transformers RMSNorm, y = x / max(||x||_2, 1e-12) * sqrt(D) * scale[c]  (no mean subtraction)
 };
 
@@ -77,7 +78,9 @@ __global__ __launch_bounds__(256) void ln_kernel(const LnArgs p) {
             y[2] = (v[i].z - mean) * rstd * (p.gain_off + sc.z) + sh.z;
             y[3] = (v[i].w - mean) * rstd * (p.gain_off + sc.w) + sh.w;
             if (p.out_f32) *reinterpret_cast<float4*>(p.out_f32 + (size_t)row * p.ldof + c) = make_float4(y[0], y[1], y[2], y[3]);
-            if (p.out_hi) {
+            if (p.out_hi && p.f16_out) {
+                store_f16x4(p.out_hi + (size_t)row * p.ldo + c, y);
+            } else if (p.out_hi) {
                 bf16x4 hi, lo;
                 split_bf16x4(y, hi, lo);
                 *reinterpret_cast<bf16x4*>(p.out_hi + (size_t)row * p.ldo + c) = hi;
@@ -200,11 +203,16 @@ __global__ __launch_bounds__(128) void final_select_kernel(const float* xstate, 
 }
 
 // fp32 [R][C] (row-major, ld = C) -> split bf16 [R_pad][C_pad] with zero fill; used by the weight packer
+// (lo == nullptr: ONE fp16 plane in hi, the weight format of the PREC_F16 GEMMs)
 __global__ __launch_bounds__(256) void pack_weight_kernel(const float* w, int R, int C, int ldw, __bf16* hi, __bf16* lo,
                                                           int C_pad) {
     const int r = blockIdx.x;
     for (int c = threadIdx.x; c < C_pad; c += 256) {
         float v = (r < R && c < C) ? w[(size_t)r * ldw + c] : 0.0f;
+        if (!lo) {
+            reinterpret_cast<_Float16*>(hi)[(size_t)r * C_pad + c] = (_Float16)v;
+            continue;
+        }
         __bf16 h, l;
         split_bf16(v, h, l);
         hi[(size_t)r * C_pad + c] = h;

@@ -31,7 +31,8 @@ struct TextBlock {
 
 struct f5hip_dit {
     f5hip_dit_config cfg;
-    int nsplit = 2;
+    int nsplit = 2;       // operand planes of the state-touching GEMMs (1 bf16, 2 split bf16)
+    bool blk_f16 = false; // gemm_planes == 3: transformer-block GEMMs (QKV, out, FF1, FF2) take one fp16 plane per operand (DiT)
     std::map<std::string, std::vector<float>> host;
     bool finalized = false;
     // packed weights
@@ -68,7 +69,7 @@ static int ceil_to(int v, int m) { return (v + m - 1) / m * m; }
 f5hip_dit* f5hip_dit_create(const f5hip_dit_config* cfg) {
     if (!cfg) { set_error("null config"); return nullptr; }
     if (cfg->dim % 128 || cfg->dim != cfg->heads * 64 || cfg->dim % 16 || cfg->text_dim % 4 || cfg->mel_dim > 128 || cfg->mel_dim % 4 ||
-        cfg->dim / 16 > 64 || (cfg->gemm_planes != 1 && cfg->gemm_planes != 2) || cfg->arch < 0 || cfg->arch > 1 ||
+        cfg->dim / 16 > 64 || cfg->gemm_planes < 1 || cfg->gemm_planes > 3 || cfg->arch < 0 || cfg->arch > 1 ||
         (cfg->arch == 1 && (cfg->conv_layers != 0 || cfg->depth % 2)) || (cfg->conv_layers > 0 && cfg->text_dim % 32)) {
         set_error("unsupported backbone geometry (need dim %% 128 == 0, dim == 64*heads, dim/16 <= 64, mel_dim <= 128, text conv needs text_dim %% 32 == 0; UNetT: even depth, no text conv)");
         return nullptr;
@@ -80,7 +81,8 @@ f5hip_dit* f5hip_dit_create(const f5hip_dit_config* cfg) {
     }
     f5hip_dit* m = new f5hip_dit();
     m->cfg = *cfg;
-    m->nsplit = cfg->gemm_planes;
+    m->nsplit = cfg->gemm_planes == 3 ? 2 : cfg->gemm_planes;
+    m->blk_f16 = cfg->gemm_planes == 3 && cfg->arch == 0;
     m->arch = cfg->arch;
     m->td_pad = ceil_to(cfg->text_dim, 32);
     m->gw = cfg->dim / 16;
@@ -234,13 +236,13 @@ int f5hip_dit_finalize(f5hip_dit* m) {
             memcpy(&wq[(size_t)i * D * D], w->data(), sizeof(float) * D * D);
             memcpy(&bq[(size_t)i * D], b->data(), sizeof(float) * D);
         }
-        if (pack_linear(m->wqkv[l], wq.data(), 3 * D, D, D, bq.data())) return -4;
+        if (pack_linear(m->wqkv[l], wq.data(), 3 * D, D, D, bq.data(), 128, m->blk_f16)) return -4;
         GETP(wo, pa + "to_out.0.weight", (int64_t)D * D); GETP(bo, pa + "to_out.0.bias", D);
-        if (pack_linear(m->wout[l], wo->data(), D, D, D, bo->data())) return -4;
+        if (pack_linear(m->wout[l], wo->data(), D, D, D, bo->data(), 128, m->blk_f16)) return -4;
         GETP(w1, pf + "ff.0.0.weight", (int64_t)F * D); GETP(b1, pf + "ff.0.0.bias", F);
-        if (pack_linear(m->wff1[l], w1->data(), F, D, D, b1->data())) return -4;
+        if (pack_linear(m->wff1[l], w1->data(), F, D, D, b1->data(), 128, m->blk_f16)) return -4;
         GETP(w2, pf + "ff.2.weight", (int64_t)D * F); GETP(b2, pf + "ff.2.bias", D);
-        if (pack_linear(m->wff2[l], w2->data(), D, F, F, b2->data())) return -4;
+        if (pack_linear(m->wff2[l], w2->data(), D, F, F, b2->data(), 128, m->blk_f16)) return -4;
         if (m->arch == 1) {
             GETP(ga, p + "1.g", D); GETP(gf, p + "3.g", D);
             if (upload_f32(&m->g_attn[l], ga->data(), D) || upload_f32(&m->g_ff[l], gf->data(), D)) return -4;
@@ -403,7 +405,11 @@ static int run_gemm_n(int nsplit, int mp, GemmArgs& a, const PackedW& W, int epi
     const long long tiles128 = (long long)(mp / 128) * (np / 128);
     const bool use2 = !conv && (g_gemm_impl == 2 || (g_gemm_impl == 0 && tiles128 <= 256 && epi != EPI_QKV));
     const bool use3 = !conv && (g_gemm_impl == 3 || (g_gemm_impl == 0 && tiles128 <= 256 && epi != EPI_QKV));
-    if (use3) {   // warp-specialised producer / consumer kernel: one tile per CU finishes soonest on it (microbench: 30.5 vs 31.0 vs 41 us)
+    if (nsplit == 3) {   // fp16 operands (one plane each): the warp-specialised kernel wins at every batch-1 shape (tools/gemm_microbench.py)
+        if (conv) { prof_end(PROF_GEMM, st); return fail(-7, "gemm: fp16 operands are not built for the implicit-GEMM convolution"); }
+        if (g_gemm_impl == 1) e = epi == EPI_QKV ? launch_gemm_t<3, 128, false, EPI_QKV>(a, mp, np, st) : launch_gemm_t<3, 128, false, EPI_GENERIC>(a, mp, np, st);
+        else e = epi == EPI_QKV ? launch_gemm3_t<3, EPI_QKV>(a, mp, np, st) : launch_gemm3_t<3, EPI_GENERIC>(a, mp, np, st);
+    } else if (use3) {   // warp-specialised producer / consumer kernel: one tile per CU finishes soonest on it (microbench: 30.5 vs 31.0 vs 41 us)
         if (nsplit == 2) e = epi == EPI_QKV ? launch_gemm3_t<2, EPI_QKV>(a, mp, np, st) : launch_gemm3_t<2, EPI_GENERIC>(a, mp, np, st);
         else e = epi == EPI_QKV ? launch_gemm3_t<1, EPI_QKV>(a, mp, np, st) : launch_gemm3_t<1, EPI_GENERIC>(a, mp, np, st);
     } else if (use2) {
@@ -435,7 +441,7 @@ static int run_gemm_n(int nsplit, int mp, GemmArgs& a, const PackedW& W, int epi
     return 0;
 }
 static int run_gemm(f5hip_dit* m, GemmArgs& a, const PackedW& W, int epi, bool conv, int bn, hipStream_t st, int m_pad = -1) {
-    return run_gemm_n(m->nsplit, m_pad > 0 ? m_pad : m->M_pad, a, W, epi, conv, bn, st);
+    return run_gemm_n(W.f16 ? 3 : m->nsplit, m_pad > 0 ? m_pad : m->M_pad, a, W, epi, conv, bn, st);
 }
 
 static int run_ln(const LnArgs& a, hipStream_t st) {
@@ -551,7 +557,7 @@ static int launch_attention(f5hip_dit* m, hipStream_t st) {
     const f5hip_dit_config& c = m->cfg;
     AttnArgs at;
     at.qk = m->qk; at.vt = m->vt; at.D = c.dim; at.ldvt = m->M_pad; at.seq_row0 = m->d_seq_row0; at.seq_len = m->d_seq_len;
-    at.seq_kvlen = m->d_seq_kvlen; at.out_hi = m->ao.hi; at.out_lo = m->nsplit == 2 ? m->ao.lo : nullptr;
+    at.seq_kvlen = m->d_seq_kvlen; at.out_hi = m->ao.hi; at.out_lo = m->nsplit == 2 ? m->ao.lo : nullptr; at.f16_out = m->blk_f16 ? 1 : 0;
     static int attn_impl = -1;
     if (attn_impl < 0) { const char* env = getenv("F5HIP_ATTN_IMPL"); attn_impl = env ? atoi(env) : 2; }
     prof_begin(PROF_ATTN, st);
@@ -651,7 +657,7 @@ static int forward_step(f5hip_dit* m, int ti, int n_blocks, hipStream_t st) {
         const float* ml = mod + (size_t)l * 6 * D;   // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
         LnArgs ln; memset(&ln, 0, sizeof(ln));
         ln.x = m->h; ln.ldx = D; ln.M = M; ln.D = D; ln.shift = ml; ln.scale = ml + D; ln.gain_off = 1.0f; ln.eps = 1e-6f;
-        ln.out_hi = m->hn.hi; ln.out_lo = m->hn.lo; ln.ldo = D;
+        ln.out_hi = m->hn.hi; ln.out_lo = m->hn.lo; ln.ldo = D; ln.f16_out = m->blk_f16 ? 1 : 0;
         CK(run_ln(ln, st));
         GemmArgs q = gemm_base(m->hn, D, m->wqkv[l], M);
         q.D = D; q.row_pos = m->d_row_pos; q.rope_cos = m->rope_cos; q.rope_sin = m->rope_sin; q.qk = m->qk; q.vt = m->vt; q.ldvt = m->M_pad;
@@ -664,7 +670,7 @@ static int forward_step(f5hip_dit* m, int ti, int n_blocks, hipStream_t st) {
         ln.shift = ml + 3 * D; ln.scale = ml + 4 * D;
         CK(run_ln(ln, st));
         GemmArgs f1 = gemm_base(m->hn, D, m->wff1[l], M);
-        f1.act = ACT_GELU_TANH; f1.out_hi = m->ff.hi; f1.out_lo = m->ff.lo; f1.ldob = F;
+        f1.act = ACT_GELU_TANH; f1.out_hi = m->ff.hi; f1.out_lo = m->ff.lo; f1.ldob = F; f1.f16_out = m->blk_f16 ? 1 : 0;
         CK(run_gemm(m, f1, m->wff1[l], EPI_GENERIC, false, 128, st));
         GemmArgs f2 = gemm_base(m->ff, F, m->wff2[l], M);
         f2.mul = ml + 5 * D; f2.res = m->h; f2.ldres = D; f2.out_f32 = m->h; f2.ldo = D;

@@ -24,12 +24,14 @@ F5_DEVICE int lds_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >>
 // ABL (diagnostics only, f5hip_debug_gemm_bench): 0 = normal, 1 = no global loads inside the k-loop, 2 = no LDS reads / MFMAs
 template <int NSPLIT, int BN, bool CONV, int EPI, int ABL = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_kernel(const GemmArgs p) {
+    constexpr int NPL = NSPLIT == 2 ? 2 : 1;   // NSPLIT = operand precision: 1 bf16, 2 split bf16 (3 MFMAs), 3 fp16 (PREC_F16)
+    constexpr bool F16 = NSPLIT == 3;
     constexpr int BM = 128;
     constexpr int WAVES_N = BN / 64, WAVES_M = 4 / WAVES_N;
     constexpr int TM = BM / WAVES_M / 32, TN = 2;
     constexpr int A_RPT = BM / 64, B_RPT = BN / 64;
     constexpr int A_PLANE = BM * 64, B_PLANE = BN * 64;
-    constexpr int STAGE = NSPLIT * (A_PLANE + B_PLANE);
+    constexpr int STAGE = NPL * (A_PLANE + B_PLANE);
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -55,11 +57,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int a_col0 = CONV ? (int)blockIdx.x * p.conv_group_cols : 0;
 
     // register staging of the next k-tile (kept in named registers: plain arrays + fully unrolled static indexing)
-    u32x4 ra[NSPLIT * A_RPT], rb[NSPLIT * B_RPT];
-    const __bf16* a_ptr[NSPLIT];
-    const __bf16* w_ptr[NSPLIT];
+    u32x4 ra[NPL * A_RPT], rb[NPL * B_RPT];
+    const __bf16* a_ptr[NPL];
+    const __bf16* w_ptr[NPL];
 #pragma unroll
-    for (int pl = 0; pl < NSPLIT; pl++) {
+    for (int pl = 0; pl < NPL; pl++) {
         a_ptr[pl] = p.A[pl] + (size_t)(m0 + lrow) * p.lda + lchunk * 8 + a_col0;
         w_ptr[pl] = p.W[pl] + (size_t)(n0 + lrow) * p.ldw + lchunk * 8;
     }
@@ -77,7 +79,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             a_off_ = kt_ * 32;                                                                                 \
         }                                                                                                      \
         _Pragma("unroll") for (int i = 0; i < A_RPT; i++) {                                                    \
-            _Pragma("unroll") for (int pl = 0; pl < NSPLIT; pl++) {                                            \
+            _Pragma("unroll") for (int pl = 0; pl < NPL; pl++) {                                            \
                 if constexpr (CONV) {                                                                          \
                     const int src_ = m0 + lrow + 64 * i + shift_;                                              \
                     const bool ok_ = src_ >= sstart[i] && src_ < send[i];                                      \
@@ -90,7 +92,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }                                                                                                  \
         }                                                                                                      \
         _Pragma("unroll") for (int i = 0; i < B_RPT; i++) {                                                    \
-            _Pragma("unroll") for (int pl = 0; pl < NSPLIT; pl++)                                              \
+            _Pragma("unroll") for (int pl = 0; pl < NPL; pl++)                                              \
                 rb[pl * B_RPT + i] = *reinterpret_cast<const u32x4*>(w_ptr[pl] + i * w_row64 + kt_ * 32);      \
         }                                                                                                      \
     }
@@ -98,11 +100,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #define STORE_TILES(STG)                                                                                       \
     {                                                                                                          \
         char* base_ = smem + (STG) * STAGE;                                                                    \
-        _Pragma("unroll") for (int pl = 0; pl < NSPLIT; pl++) {                                                \
+        _Pragma("unroll") for (int pl = 0; pl < NPL; pl++) {                                                \
             _Pragma("unroll") for (int i = 0; i < A_RPT; i++)                                                  \
                 *reinterpret_cast<u32x4*>(base_ + pl * A_PLANE + lds_off(lrow + 64 * i, lchunk)) = ra[pl * A_RPT + i]; \
             _Pragma("unroll") for (int i = 0; i < B_RPT; i++)                                                  \
-                *reinterpret_cast<u32x4*>(base_ + NSPLIT * A_PLANE + pl * B_PLANE + lds_off(lrow + 64 * i, lchunk)) = rb[pl * B_RPT + i]; \
+                *reinterpret_cast<u32x4*>(base_ + NPL * A_PLANE + pl * B_PLANE + lds_off(lrow + 64 * i, lchunk)) = rb[pl * B_RPT + i]; \
         }                                                                                                      \
     }
 
@@ -139,16 +141,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const char* base = smem + (kt & 1) * STAGE;
 #pragma unroll
         for (int s = 0; s < (ABL == 2 ? 0 : 2); s++) {
-            bf16x8 af[NSPLIT][TM], bf[NSPLIT][TN];
+            bf16x8 af[NPL][TM], bf[NPL][TN];
             const int chunk = s * 2 + fh;
 #pragma unroll
-            for (int pl = 0; pl < NSPLIT; pl++) {
+            for (int pl = 0; pl < NPL; pl++) {
 #pragma unroll
                 for (int i = 0; i < TM; i++)
                     af[pl][i] = *reinterpret_cast<const bf16x8*>(base + pl * A_PLANE + lds_off(wm * (TM * 32) + i * 32 + fr, chunk));
 #pragma unroll
                 for (int j = 0; j < TN; j++)
-                    bf[pl][j] = *reinterpret_cast<const bf16x8*>(base + NSPLIT * A_PLANE + pl * B_PLANE + lds_off(wn * 64 + j * 32 + fr, chunk));
+                    bf[pl][j] = *reinterpret_cast<const bf16x8*>(base + NPL * A_PLANE + pl * B_PLANE + lds_off(wn * 64 + j * 32 + fr, chunk));
             }
 #pragma unroll
             for (int i = 0; i < TM; i++)
@@ -158,7 +160,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[0][j], acc[i][j], 0, 0, 0);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[1][j], acc[i][j], 0, 0, 0);
                     }
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[0][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = mfma_32x32x16<F16>(af[0][i], bf[0][j], acc[i][j]);
                 }
         }
         STAMP(2);   // LDS reads + MFMAs
@@ -188,7 +190,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 template <int NSPLIT, int BN, bool CONV, int EPI, int ABL = 0>
 static hipError_t launch_gemm_t(const GemmArgs& a, int m_pad, int n_pad, hipStream_t st) {
     constexpr int EPI_LDS = (128 / (4 / (BN / 64)) / 32) * 2 * 4096 * 4;   // 4 waves x (TM x TN) x 4 KiB epilogue slabs
-    constexpr int LDS = 2 * NSPLIT * (128 + BN) * 64 < EPI_LDS ? EPI_LDS : 2 * NSPLIT * (128 + BN) * 64;
+    constexpr int NPL = NSPLIT == 2 ? 2 : 1;
+    constexpr int LDS = 2 * NPL * (128 + BN) * 64 < EPI_LDS ? EPI_LDS : 2 * NPL * (128 + BN) * 64;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<NSPLIT, BN, CONV, EPI, ABL>),

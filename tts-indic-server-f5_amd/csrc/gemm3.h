@@ -16,8 +16,10 @@
 // ABL (diagnostics only): 0 = normal, 1 = producers issue no DMA (consumers read whatever is in LDS), 2 = consumers skip the MFMAs
 template <int NSPLIT, int EPI, int ABL = 0>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm3_kernel(const GemmArgs p) {
+    constexpr int NPL = NSPLIT == 2 ? 2 : 1;   // NSPLIT = operand precision: 1 bf16, 2 split bf16 (3 MFMAs), 3 fp16
+    constexpr bool F16 = NSPLIT == 3;
     constexpr int BM = 128, BN = 128, TM = 2, TN = 2, NST = 4;
-    constexpr int A_PLANE = BM * 64, B_PLANE = BN * 64, STAGE = NSPLIT * (A_PLANE + B_PLANE);
+    constexpr int A_PLANE = BM * 64, B_PLANE = BN * 64, STAGE = NPL * (A_PLANE + B_PLANE);
     constexpr int P = STAGE / 1024 / 4;   // DMA pieces per producer wave per k-tile
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -33,8 +35,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int j = 0; j < P; j++) {
             const int off = (pw * P + j) * 1024;
-            const bool isA = off < NSPLIT * A_PLANE;
-            const int rel = isA ? off : off - NSPLIT * A_PLANE;
+            const bool isA = off < NPL * A_PLANE;
+            const int rel = isA ? off : off - NPL * A_PLANE;
             const int plane_bytes = isA ? A_PLANE : B_PLANE;
             const int pl = rel / plane_bytes;
             const int row = (rel - pl * plane_bytes) / 64 + (lane >> 2);
@@ -77,22 +79,22 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
     // Software-pipelined fragments: the LDS reads of the NEXT half k-step (16 k) are always issued before the 12 MFMAs of the
     // current one, so with one consumer wave per SIMD the LDS latency hides behind 384 MFMA cycles.
-    bf16x8 fa[2][NSPLIT][TM], fb[2][NSPLIT][TN];
+    bf16x8 fa[2][NPL][TM], fb[2][NPL][TN];
     auto read_frags = [&](int buf, const char* st, int s) {
         const int chunk = s * 2 + fh;
 #pragma unroll
-        for (int pl = 0; pl < NSPLIT; pl++) {
+        for (int pl = 0; pl < NPL; pl++) {
 #pragma unroll
             for (int i = 0; i < TM; i++)
                 fa[buf][pl][i] = *reinterpret_cast<const bf16x8*>(st + pl * A_PLANE + lds_off2(wm * 64 + i * 32 + fr, chunk));
 #pragma unroll
             for (int j = 0; j < TN; j++)
-                fb[buf][pl][j] = *reinterpret_cast<const bf16x8*>(st + NSPLIT * A_PLANE + pl * B_PLANE + lds_off2(wn * 64 + j * 32 + fr, chunk));
+                fb[buf][pl][j] = *reinterpret_cast<const bf16x8*>(st + NPL * A_PLANE + pl * B_PLANE + lds_off2(wn * 64 + j * 32 + fr, chunk));
         }
     };
     auto mfma_frags = [&](int buf) {
         if constexpr (ABL == 2) {
-            asm volatile("" :: "v"(fa[buf][0][0]), "v"(fb[buf][0][0]), "v"(fa[buf][NSPLIT - 1][TM - 1]), "v"(fb[buf][NSPLIT - 1][TN - 1]));
+            asm volatile("" :: "v"(fa[buf][0][0]), "v"(fb[buf][0][0]), "v"(fa[buf][NPL - 1][TM - 1]), "v"(fb[buf][NPL - 1][TN - 1]));
             return;
         }
 #pragma unroll
@@ -103,7 +105,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[buf][1][i], fb[buf][0][j], acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[buf][0][i], fb[buf][1][j], acc[i][j], 0, 0, 0);
                 }
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[buf][0][i], fb[buf][0][j], acc[i][j], 0, 0, 0);
+                acc[i][j] = mfma_32x32x16<F16>(fa[buf][0][i], fb[buf][0][j], acc[i][j]);
             }
     };
     unsigned long long ts[4] = {0, 0, 0, 0};
@@ -143,7 +145,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 template <int NSPLIT, int EPI, int ABL = 0>
 static hipError_t launch_gemm3_t(const GemmArgs& a, int m_pad, int n_pad, hipStream_t st) {
-    constexpr int LDS = 4 * NSPLIT * (128 + 128) * 64 > 65536 ? 4 * NSPLIT * (128 + 128) * 64 : 65536;
+    constexpr int NPL = NSPLIT == 2 ? 2 : 1;
+    constexpr int LDS = 4 * NPL * (128 + 128) * 64 > 65536 ? 4 * NPL * (128 + 128) * 64 : 65536;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm3_kernel<NSPLIT, EPI, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);

@@ -37,6 +37,7 @@ struct GemmArgs {
     __bf16* out_hi;
     __bf16* out_lo;
     int ldob;
+    int f16_out;          // 1: out_hi receives ONE fp16 plane (A operand of a PREC_F16 GEMM); only for the (no residual, no fp32 output) epilogues
     // QKV epilogue
     int D;                   // model dim (N == 3 D)
     const int* row_pos;      // [M_pad] frame index inside the row's sequence
@@ -56,7 +57,7 @@ struct GemmArgs {
 // GUARD = false is the interior fast path (whole wave tile inside M x N, no column groups, no row_keep): straight-line code, so
 // the compiler counts vmcnt exactly -- all residual loads in flight, stores never waited on.  With per-row-group exec
 // branches (GUARD = true) it falls back to s_waitcnt vmcnt(0) per group, which serialises every store's latency.
-template <int ACT, int WN, int ROWS, bool RES, bool OUTF, bool OUTS, bool GUARD>
+template <int ACT, int WN, int ROWS, bool RES, bool OUTF, int OUTS, bool GUARD>   // OUTS: 0 none, 1 split bf16, 2 one fp16 plane
 F5_DEVICE void epi_generic_rows_t(const GemmArgs& p, const float* stg, int m_base, int n_base, int lane) {
     constexpr int LPR = WN / 4, RPP = 64 / LPR, NQ = ROWS / RPP;
     const int c4 = (lane % LPR) * 4, r0 = lane / LPR;
@@ -85,7 +86,7 @@ F5_DEVICE void epi_generic_rows_t(const GemmArgs& p, const float* stg, int m_bas
     }
     float* of = OUTF ? p.out_f32 + (size_t)mrow * p.ldo + no : nullptr;
     __bf16* oh = OUTS ? p.out_hi + (size_t)mrow * p.ldob + no : nullptr;
-    __bf16* ol = OUTS && (!GUARD || p.out_lo) ? p.out_lo + (size_t)mrow * p.ldob + no : nullptr;
+    __bf16* ol = OUTS == 1 && (!GUARD || p.out_lo) ? p.out_lo + (size_t)mrow * p.ldob + no : nullptr;
     const size_t sf = (size_t)RPP * p.ldo, sb = (size_t)RPP * p.ldob;
 #pragma unroll
     for (int q = 0; q < NQ; q++) {
@@ -98,7 +99,10 @@ F5_DEVICE void epi_generic_rows_t(const GemmArgs& p, const float* stg, int m_bas
         v = v * mv + rs[q];
         if (!GUARD || (nok && mrow + q * RPP < p.M)) {
             if (OUTF) *reinterpret_cast<f32x4*>(of + q * sf) = v;
-            if (OUTS) {
+            if (OUTS == 2) {
+                const float vv[4] = {v[0], v[1], v[2], v[3]};
+                store_f16x4(oh + q * sb, vv);
+            } else if (OUTS == 1) {
                 bf16x4 hi, lo;
                 const float vv[4] = {v[0], v[1], v[2], v[3]};
                 split_bf16x4(vv, hi, lo);
@@ -114,26 +118,28 @@ F5_DEVICE void epi_generic_rows_g(const GemmArgs& p, const float* stg, int m_bas
     const bool res = p.res != nullptr, outf = p.out_f32 != nullptr, outs = p.out_hi != nullptr;
     if (ACT == ACT_NONE) {   // residual / plain projections: every output combination occurs
         if (res) {
-            if (outf && outs) epi_generic_rows_t<ACT, WN, ROWS, true, true, true, GUARD>(p, stg, m_base, n_base, lane);
-            else if (outf) epi_generic_rows_t<ACT, WN, ROWS, true, true, false, GUARD>(p, stg, m_base, n_base, lane);
-            else epi_generic_rows_t<ACT, WN, ROWS, true, false, true, GUARD>(p, stg, m_base, n_base, lane);
+            if (outf && outs) epi_generic_rows_t<ACT, WN, ROWS, true, true, 1, GUARD>(p, stg, m_base, n_base, lane);
+            else if (outf) epi_generic_rows_t<ACT, WN, ROWS, true, true, 0, GUARD>(p, stg, m_base, n_base, lane);
+            else epi_generic_rows_t<ACT, WN, ROWS, true, false, 1, GUARD>(p, stg, m_base, n_base, lane);
         } else {
-            if (outf && outs) epi_generic_rows_t<ACT, WN, ROWS, false, true, true, GUARD>(p, stg, m_base, n_base, lane);
-            else if (outf) epi_generic_rows_t<ACT, WN, ROWS, false, true, false, GUARD>(p, stg, m_base, n_base, lane);
-            else epi_generic_rows_t<ACT, WN, ROWS, false, false, true, GUARD>(p, stg, m_base, n_base, lane);
+            if (outf && outs) epi_generic_rows_t<ACT, WN, ROWS, false, true, 1, GUARD>(p, stg, m_base, n_base, lane);
+            else if (outf) epi_generic_rows_t<ACT, WN, ROWS, false, true, 0, GUARD>(p, stg, m_base, n_base, lane);
+            else if (p.f16_out) epi_generic_rows_t<ACT, WN, ROWS, false, false, 2, GUARD>(p, stg, m_base, n_base, lane);
+            else epi_generic_rows_t<ACT, WN, ROWS, false, false, 1, GUARD>(p, stg, m_base, n_base, lane);
         }
     } else {                 // activations: (no residual -> split or fp32) and (residual -> fp32) are the combinations in use
-        if (res) epi_generic_rows_t<ACT, WN, ROWS, true, true, false, GUARD>(p, stg, m_base, n_base, lane);
-        else if (outs && !outf) epi_generic_rows_t<ACT, WN, ROWS, false, false, true, GUARD>(p, stg, m_base, n_base, lane);
-        else if (outf && !outs) epi_generic_rows_t<ACT, WN, ROWS, false, true, false, GUARD>(p, stg, m_base, n_base, lane);
-        else epi_generic_rows_t<ACT, WN, ROWS, false, true, true, GUARD>(p, stg, m_base, n_base, lane);
+        if (res) epi_generic_rows_t<ACT, WN, ROWS, true, true, 0, GUARD>(p, stg, m_base, n_base, lane);
+        else if (outs && !outf && p.f16_out) epi_generic_rows_t<ACT, WN, ROWS, false, false, 2, GUARD>(p, stg, m_base, n_base, lane);
+        else if (outs && !outf) epi_generic_rows_t<ACT, WN, ROWS, false, false, 1, GUARD>(p, stg, m_base, n_base, lane);
+        else if (outf && !outs) epi_generic_rows_t<ACT, WN, ROWS, false, true, 0, GUARD>(p, stg, m_base, n_base, lane);
+        else epi_generic_rows_t<ACT, WN, ROWS, false, true, 1, GUARD>(p, stg, m_base, n_base, lane);
     }
 }
 
 template <int ACT, int WN, int ROWS>
 F5_DEVICE void epi_generic_rows(const GemmArgs& p, const float* stg, int m_base, int n_base, int lane) {
     // wave-uniform: interior tile with both split planes (or none) and no per-row / per-group special cases
-    const bool interior = m_base + ROWS <= p.M && n_base + WN <= p.N && !p.group_w && !p.row_keep && (!p.out_hi || p.out_lo);
+    const bool interior = m_base + ROWS <= p.M && n_base + WN <= p.N && !p.group_w && !p.row_keep && (!p.out_hi || p.out_lo || p.f16_out);
     if (interior) epi_generic_rows_g<ACT, WN, ROWS, false>(p, stg, m_base, n_base, lane);
     else epi_generic_rows_g<ACT, WN, ROWS, true>(p, stg, m_base, n_base, lane);
 }

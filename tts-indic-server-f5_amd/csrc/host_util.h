@@ -37,6 +37,7 @@ struct DevBuf { void* ptr = nullptr; };
 struct PackedW {
     __bf16* hi = nullptr; __bf16* lo = nullptr; float* bias = nullptr;
     int n = 0, k = 0, n_pad = 0, k_pad = 0, ld = 0;
+    bool f16 = false;   // hi holds one fp16 plane, lo == nullptr
 };
 
 template <typename T> static void dev_free(T* p) { if (p) (void)hipFree((void*)p); }
@@ -81,12 +82,13 @@ static void host_split_bf16(float x, uint16_t& hi, uint16_t& lo) {
 }
 
 // W [N][K] fp32 host (row stride ldw) -> split bf16 device [ceil128(N)][ceil32(K)], bias -> fp32 [ceil128(N)]
-static int pack_linear(PackedW& out, const float* w, int N, int K, int ldw, const float* bias, int n_align = 128) {
+static int pack_linear(PackedW& out, const float* w, int N, int K, int ldw, const float* bias, int n_align = 128, bool f16 = false) {
+    out.f16 = f16;
     out.n = N; out.k = K; out.n_pad = (N + n_align - 1) / n_align * n_align; out.k_pad = (K + 31) / 32 * 32; out.ld = out.k_pad;
     const size_t np = (size_t)out.n_pad * out.k_pad;
     float* tmp = nullptr;
     if (hipMalloc((void**)&tmp, (size_t)N * ldw * sizeof(float)) != hipSuccess) return fail(-4, "hipMalloc pack staging");
-    if (hipMalloc((void**)&out.hi, np * 2) != hipSuccess || hipMalloc((void**)&out.lo, np * 2) != hipSuccess) {
+    if (hipMalloc((void**)&out.hi, np * 2) != hipSuccess || (!f16 && hipMalloc((void**)&out.lo, np * 2) != hipSuccess)) {
         dev_free(tmp);
         return fail(-4, "hipMalloc packed weight %d x %d", out.n_pad, out.k_pad);
     }

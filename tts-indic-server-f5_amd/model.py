@@ -68,14 +68,14 @@ def _ptr(t):
 
 
 class F5HipModel:
-    def __init__(self, arch: DiTArch | UNetTArch, state_dict: dict, vocab_char_map: dict | None = None, gemm_planes: int = 2,
+    def __init__(self, arch: DiTArch | UNetTArch, state_dict: dict, vocab_char_map: dict | None = None, gemm_planes: int = 3,
                  device: str | torch.device = "cuda:0", mel_spec_type: str = "vocos"):
         self.arch = arch
         self.device = torch.device(device)
         self.vocab_char_map = vocab_char_map
         self.mel_spec_type = mel_spec_type
         self.num_channels = arch.mel_dim
-        self.gemm_planes = gemm_planes
+        self.gemm_planes = gemm_planes   # 3 = mixed parity mode (default), 2 = bf16x3 everywhere, 1 = plain bf16 (include/f5hip.h)
         self._lib = _lib.lib()
         if self.device.type != "cuda":
             raise _lib.F5HipError("F5HipModel needs a HIP device (no CPU fallback)")
