@@ -28,9 +28,28 @@ def build(force: bool = False, verbose: bool = True) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", LIB,
            os.path.join(CSRC, "f5hip.hip")]
+    # -Rpass-analysis=kernel-resource-usage: per-kernel VGPR / scratch report.  A hot kernel that touches scratch pays a
+    # scratch set-up per wave plus the spills (a run-time index into the by-value argument struct once cost every GEMM 7 us).
+    cmd.insert(-1, "-Rpass-analysis=kernel-resource-usage")
     if verbose:
         print("[build]", " ".join(cmd), flush=True)
-    subprocess.run(cmd, check=True)
+    r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
+    report, name = [], None
+    for line in r.stderr.splitlines():
+        if "Function Name:" in line:
+            name = line.split("Function Name:")[1].split("[-R")[0].strip()
+        elif "ScratchSize [bytes/lane]:" in line and name:
+            report.append((name, int(line.split("ScratchSize [bytes/lane]:")[1].split()[0])))
+            name = None
+    if r.returncode != 0:
+        sys.stderr.write("\n".join(l for l in r.stderr.splitlines() if "remark:" not in l) + "\n")
+        raise subprocess.CalledProcessError(r.returncode, cmd)
+    with open(os.path.join(CSRC, "kernel_resources.txt"), "w") as f:
+        for n, sc in report:
+            f.write(f"{sc:6d} B scratch  {n}\n")
+    hot = [n for n, sc in report if sc and any(k in n for k in ("gemm", "attn", "ln_kernel"))]
+    if hot:
+        raise RuntimeError("hot kernels use scratch memory: " + ", ".join(hot))
     return LIB
 
 

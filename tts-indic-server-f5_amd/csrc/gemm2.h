@@ -57,7 +57,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int pl = rel / plane_bytes;
         const int row = (rel - pl * plane_bytes) / 64 + (lane >> 2);   // row inside the plane (piece = 16 rows x 64 B)
         const int chunk = (lane & 3) ^ ((row >> 2) & 3);               // logical 16-B chunk that lands in physical slot lane & 3
-        const __bf16* base = isA ? p.A[pl] + (size_t)(m0 + row) * p.lda : p.W[pl] + (size_t)(n0 + row) * p.ldw;
+        // explicit selects: a run-time index into the by-value argument struct makes hipcc copy all of GemmArgs to scratch
+        const __bf16* ap = (NSPLIT == 2 && pl) ? p.A[1] : p.A[0];
+        const __bf16* wp = (NSPLIT == 2 && pl) ? p.W[1] : p.W[0];
+        const __bf16* base = isA ? ap + (size_t)(m0 + row) * p.lda : wp + (size_t)(n0 + row) * p.ldw;
         gsrc[j] = reinterpret_cast<const char*>(base + chunk * 8);
     }
     auto issue_tile = [&](int kt) {
