@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "csrc", "libf5hip.so")
+LIB_PATH = os.environ.get("F5HIP_LIB") or os.path.join(HERE, "csrc", "libf5hip.so")   # F5HIP_LIB: A/B builds of the same ABI (diagnostics)
 
 _lib = None
 

@@ -20,6 +20,7 @@ struct AttnArgs {
     __bf16* out_hi;     // [M_pad][D]
     __bf16* out_lo;     // may be null
     int f16_out;        // 1: out_hi receives one fp16 plane (A operand of the fp16 out-projection GEMM)
+    unsigned long long* dbg;   // diagnostics (attn3): per-phase s_memtime totals of wave 0 of workgroup (0,0,0), or null
 };
 
 F5_DEVICE int lds_off128(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }

@@ -88,3 +88,33 @@ extern "C" int f5hip_debug_gemm_bench(int32_t M, int32_t N, int32_t K, int32_t p
     if (e != hipSuccess) return fail(-7, "debug_gemm_bench launch: %s", hipGetErrorString(e));
     return 0;
 }
+
+// per-phase cycle totals of one wave of attn3 (ring wait + barrier | QK^T issue | softmax + PV) and the kernel's average duration
+extern "C" int f5hip_debug_attn_stamps(int32_t n, int32_t heads, int32_t iters, unsigned long long* out, double* avg_us) {
+    const int D = heads * 64, n_seq = 2, pitch = (n + 127) / 128 * 128, M = n_seq * pitch + 256;
+    float* f = nullptr; __bf16 *qk = nullptr, *vt = nullptr, *oh = nullptr, *ol = nullptr, *lo_tmp = nullptr; int* meta = nullptr; unsigned long long* dbg = nullptr;
+    const size_t nq = (size_t)M * 2 * D, nv = (size_t)D * M;
+    if (hipMalloc(&f, nq * 4) || hipMalloc(&qk, nq * 2) || hipMalloc(&vt, nv * 2) || hipMalloc(&oh, (size_t)M * D * 2) || hipMalloc(&ol, (size_t)M * D * 2) ||
+        hipMalloc(&meta, 6 * sizeof(int)) || hipMalloc(&dbg, 64) || hipMalloc(&lo_tmp, nq * 2)) return fail(-5, "attn stamps: hipMalloc");
+    hipLaunchKernelGGL(fill_pattern_kernel, dim3((nq + 255) / 256), dim3(256), 0, 0, f, nq, 3u);
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(M), dim3(256), 0, 0, f, M, 2 * D, 2 * D, qk, lo_tmp, 2 * D);   // hi plane = bf16(q | k); the lo plane is discarded
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(D), dim3(256), 0, 0, f, D, M, M, vt, lo_tmp, M);
+    const int h_meta[6] = {0, pitch, n, n, n, n};
+    hipMemcpy(meta, h_meta, sizeof(h_meta), hipMemcpyHostToDevice);
+    hipMemset(dbg, 0, 64);
+    AttnArgs at; memset(&at, 0, sizeof(at));
+    at.qk = qk; at.vt = vt; at.D = D; at.ldvt = M; at.seq_row0 = meta; at.seq_len = meta + 2; at.seq_kvlen = meta + 4; at.out_hi = oh; at.out_lo = ol; at.dbg = dbg;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int it = -2; it < iters; it++) {
+        if (it == 0) hipEventRecord(e0, 0);
+        hipLaunchKernelGGL(attn3_fwd_kernel, dim3((n + 255) / 256, heads, n_seq), dim3(512), 0, 0, at);
+    }
+    hipEventRecord(e1, 0); hipEventSynchronize(e1);
+    float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+    if (avg_us) *avg_us = (double)ms * 1e3 / iters;
+    hipMemcpy(out, dbg, 32, hipMemcpyDeviceToHost);
+    hipError_t e = hipGetLastError();
+    for (void* p : {(void*)f, (void*)qk, (void*)vt, (void*)oh, (void*)ol, (void*)meta, (void*)dbg, (void*)lo_tmp}) hipFree(p);
+    if (e != hipSuccess) return fail(-7, "attn stamps: %s", hipGetErrorString(e));
+    return 0;
+}

@@ -13,11 +13,13 @@
 
 #include "attn.h"
 #include "attn2.h"
+#include "attn3.h"
 #include "common.h"
 #include "elementwise.h"
 #include "gemm.h"
 #include "gemm2.h"
 #include "gemm3.h"
+#include "gemm4.h"
 #include "host_util.h"
 
 // =================================================================================================
@@ -32,6 +34,7 @@ struct TextBlock {
 struct f5hip_dit {
     f5hip_dit_config cfg;
     int nsplit = 2;       // operand planes of the state-touching GEMMs (1 bf16, 2 split bf16)
+    StreamKWs sk;         // stream-K partial-tile slots + flags (gemm4.h), owned by the handle: launches of one handle are stream-ordered
     bool blk_f16 = false; // gemm_planes == 3: transformer-block GEMMs (QKV, out, FF1, FF2) take one fp16 plane per operand (DiT)
     std::map<std::string, std::vector<float>> host;
     bool finalized = false;
@@ -104,6 +107,7 @@ void f5hip_dit_destroy(f5hip_dit* m) {
     }
     for (float* p : {m->text_emb, m->text_pos, m->rope_cos, m->rope_sin}) dev_free(p);
     dev_free(m->ws.ptr);
+    streamk_ws_free(m->sk);
     dev_free(m->meta);
     delete m;
 }
@@ -390,7 +394,7 @@ static GemmArgs gemm_base(const Plane2& A, int lda, const PackedW& W, int M) {
 
 static int g_gemm_impl = -1;   // 0 = automatic, 1 = register-staged 4-wave kernel only (gemm.h), 2 = LDS-DMA ring kernel wherever applicable (gemm2.h)
 
-static int run_gemm_n(int nsplit, int mp, GemmArgs& a, const PackedW& W, int epi, bool conv, int bn, hipStream_t st) {
+static int run_gemm_n(int nsplit, int mp, GemmArgs& a, const PackedW& W, int epi, bool conv, int bn, hipStream_t st, StreamKWs* sk = nullptr) {
     hipError_t e;
     const int np = W.n_pad;
     if (mp % 128 || np % bn || a.K % 32) return fail(-7, "gemm: bad padded shape %d x %d x %d", mp, np, a.K);
@@ -405,7 +409,16 @@ static int run_gemm_n(int nsplit, int mp, GemmArgs& a, const PackedW& W, int epi
     const long long tiles128 = (long long)(mp / 128) * (np / 128);
     const bool use2 = !conv && (g_gemm_impl == 2 || (g_gemm_impl == 0 && tiles128 <= 256 && epi != EPI_QKV));
     const bool use3 = !conv && (g_gemm_impl == 3 || (g_gemm_impl == 0 && tiles128 <= 256 && epi != EPI_QKV));
-    if (nsplit == 3) {   // fp16 operands (one plane each): the warp-specialised kernel wins at every batch-1 shape (tools/gemm_microbench.py)
+    // stream-K (gemm4.h): every CU gets the same number of k-steps.  Opt-in only (F5HIP_GEMM_IMPL=4): parity-green, but measured
+    // 5-25 % SLOWER than the data-parallel kernels at every C2 shape (rocprof: QKV 43.5 vs 39.9 us, out 21.3 vs 17, FF1 32.6 vs 29.2):
+    // the partial-tile exchange costs more than the balance wins while the k-loop is bound by operand traffic, not by the MFMAs.
+    const int nk32 = a.K >> 5;
+    const bool can4 = sk && !conv && nsplit != 2 && np % 128 == 0 && nk32 >= 16 && tiles128 >= 64;   // (the split-bf16 instantiation spills: not built)
+    if (can4 && g_gemm_impl == 4) {
+        if (streamk_ws_init(*sk)) { prof_end(PROF_GEMM, st); return fail(-5, "stream-K workspace"); }
+        if (nsplit == 3) e = epi == EPI_QKV ? launch_gemm4_t<3, EPI_QKV>(a, mp, np, *sk, st) : launch_gemm4_t<3, EPI_GENERIC>(a, mp, np, *sk, st);
+        else e = epi == EPI_QKV ? launch_gemm4_t<1, EPI_QKV>(a, mp, np, *sk, st) : launch_gemm4_t<1, EPI_GENERIC>(a, mp, np, *sk, st);
+    } else if (nsplit == 3) {   // fp16 operands (one plane each): the warp-specialised kernel wins at every batch-1 shape (tools/gemm_microbench.py)
         if (conv) { prof_end(PROF_GEMM, st); return fail(-7, "gemm: fp16 operands are not built for the implicit-GEMM convolution"); }
         if (g_gemm_impl == 1) e = epi == EPI_QKV ? launch_gemm_t<3, 128, false, EPI_QKV>(a, mp, np, st) : launch_gemm_t<3, 128, false, EPI_GENERIC>(a, mp, np, st);
         else e = epi == EPI_QKV ? launch_gemm3_t<3, EPI_QKV>(a, mp, np, st) : launch_gemm3_t<3, EPI_GENERIC>(a, mp, np, st);
@@ -441,7 +454,7 @@ static int run_gemm_n(int nsplit, int mp, GemmArgs& a, const PackedW& W, int epi
     return 0;
 }
 static int run_gemm(f5hip_dit* m, GemmArgs& a, const PackedW& W, int epi, bool conv, int bn, hipStream_t st, int m_pad = -1) {
-    return run_gemm_n(W.f16 ? 3 : m->nsplit, m_pad > 0 ? m_pad : m->M_pad, a, W, epi, conv, bn, st);
+    return run_gemm_n(W.f16 ? 3 : m->nsplit, m_pad > 0 ? m_pad : m->M_pad, a, W, epi, conv, bn, st, &m->sk);
 }
 
 static int run_ln(const LnArgs& a, hipStream_t st) {
@@ -555,14 +568,15 @@ static int precompute_time(f5hip_dit* m, const float* t_host, int n_t, hipStream
 
 static int launch_attention(f5hip_dit* m, hipStream_t st) {
     const f5hip_dit_config& c = m->cfg;
-    AttnArgs at;
+    AttnArgs at; memset(&at, 0, sizeof(at));
     at.qk = m->qk; at.vt = m->vt; at.D = c.dim; at.ldvt = m->M_pad; at.seq_row0 = m->d_seq_row0; at.seq_len = m->d_seq_len;
     at.seq_kvlen = m->d_seq_kvlen; at.out_hi = m->ao.hi; at.out_lo = m->nsplit == 2 ? m->ao.lo : nullptr; at.f16_out = m->blk_f16 ? 1 : 0;
     static int attn_impl = -1;
-    if (attn_impl < 0) { const char* env = getenv("F5HIP_ATTN_IMPL"); attn_impl = env ? atoi(env) : 2; }
+    if (attn_impl < 0) { const char* env = getenv("F5HIP_ATTN_IMPL"); attn_impl = env ? atoi(env) : 3; }
     prof_begin(PROF_ATTN, st);
     if (attn_impl == 1) hipLaunchKernelGGL(attn_fwd_kernel, dim3((m->max_len + 127) / 128, c.heads, m->n_seq), dim3(256), 0, st, at);
-    else hipLaunchKernelGGL(attn2_fwd_kernel, dim3((m->max_len + 255) / 256, c.heads, m->n_seq), dim3(512), 0, st, at);
+    else if (attn_impl == 2) hipLaunchKernelGGL(attn2_fwd_kernel, dim3((m->max_len + 255) / 256, c.heads, m->n_seq), dim3(512), 0, st, at);
+    else hipLaunchKernelGGL(attn3_fwd_kernel, dim3((m->max_len + 255) / 256, c.heads, m->n_seq), dim3(512), 0, st, at);
     prof_end(PROF_ATTN, st);
     CKL("attention");
     return 0;

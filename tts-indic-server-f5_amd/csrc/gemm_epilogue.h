@@ -204,7 +204,7 @@ F5_DEVICE void epi_qk_rows(const GemmArgs& p, const float* stg, int m_base, int 
 // the slab is wave-private, DS operations of one wave execute in order, so a wavefront-scope fence (compiler ordering
 // only, no instruction) is all that separates the transposing writes from the row reads.  The whole sub-tile is staged
 // at once so the accumulators are dead before the row phase (its residual prefetch needs their registers).
-template <int EPI, int TM, int TN>
+template <int EPI, int TM, int TN, bool BAR = true>   // BAR = false: the slab does not alias the k-loop stages (gemm4.h), no workgroup barrier
 F5_DEVICE void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[TM][TN], float* slab, int m_wave, int n_wave, int n_blk, int lane,
                               unsigned long long* dbg = nullptr) {
     constexpr int WN = TN * 32, ROWS = TM * 32;
@@ -220,7 +220,7 @@ F5_DEVICE void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[TM][TN], float* sl
     }
     EPI_STAMP(-1);
     const int fr = lane & 31, fh = lane >> 5;
-    __syncthreads();
+    if (BAR) __syncthreads();
     EPI_STAMP(0);
     if (EPI == EPI_QKV && n_blk >= 2 * p.D) {
         // V block: written transposed ([feature][token]) straight from the accumulators, 4 tokens = 8 bytes per store
