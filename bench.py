@@ -58,6 +58,8 @@ def cpu_baseline(sd, vsd, cond, text, y0, n_threads):
             "rtf": round(wall / ((N_TOTAL - N_REF - 1) * 256 / 24000.0), 3)}
 
 
+PMC_TRAFFIC_BYTES_PER_LAUNCH = 79.6e6   # 67.2 MB fetch + 12.4 MB write per launch (algorithmic minimum: 30-39 MB)
+
 GEMM_MODES = {
     1: "plain bf16 everywhere (misses the 1e-3 mel bound)",
     2: "bf16x3 split everywhere (hi*hi+hi*lo+lo*hi, fp32 acc) - strict parity mode, 1.1e-4 mel RMS",
@@ -177,8 +179,11 @@ def main():
             "config": {"workload": f"F5-TTS-Base, 32 NFE + CFG=2.0 + sway -1, {'BigVGAN' if bigv is not None else 'Vocos'}, {B} x 10 s utterance (N=1404, 936 generated frames) per GPU per step",
                        "gemm_mode": GEMM_MODES[args.gemm_planes],
                        "attention": "bf16 MFMA, fp32 softmax", "parallelism": f"utterance-sharded x{world}, RCCL broadcast of ref latents"},
-            "roofline": {"bound": "mfma", "kernel": "gemm_kernel (all instantiations)", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+            "roofline": {"bound": "mfma", "kernel": "gemm3_kernel / gemm_kernel (all GEMM instantiations)", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
+                         # memory-side bytes per GEMM launch from the PMC passes committed in profiles/ (not collected live: rocprofv3 only)
+                         "traffic": PMC_TRAFFIC_BYTES_PER_LAUNCH if (args.gemm_planes == 3 and B == 1) else None,
+                         "traffic_source": "profiles/r01_pmc_hbm_traffic.txt: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate passes, mean over the fp16 block GEMMs",
                          "avg_launch_us": round(g["total_ms"] * 1e3 / max(1, g["launches"]), 2), "launches": g["launches"],
                          "executed_mfma_x": {1: 1, 2: 3, 3: 1.02}[args.gemm_planes],
                          "attn_tflops": round(attn_tf, 1), "attn_frac": round(attn_tf / PEAK_BF16_TFLOPS, 4)},
