@@ -89,3 +89,89 @@ def test_resample_known_answers():
     assert infer.resample_sinc_hann(x, 24000, 24000) is x
     z = infer.resample_sinc_hann(torch.randn(2, 44100), 44100, 24000)
     assert z.shape == (2, 24000) and torch.isfinite(z).all()
+
+
+# ---------------------------------------------------------------- reference-audio pre-step (audio_prep.py, F/infer/utils_infer.py:263-350)
+def _tone(ms, rate=24000, amp=8000, f=220.0):
+    import numpy as np
+    n = int(rate * ms / 1000)
+    return (amp * np.sin(2 * np.pi * f * np.arange(n) / rate)).astype(np.int16)
+
+
+def _zeros(ms, rate=24000):
+    import numpy as np
+    return np.zeros(int(rate * ms / 1000), dtype=np.int16)
+
+
+def _write_wav(path, x, rate=24000):
+    import wave
+    with wave.open(str(path), "wb") as f:
+        f.setnchannels(1); f.setsampwidth(2); f.setframerate(rate)
+        f.writeframes(x.astype("<i2").tobytes())
+
+
+def test_pcm_segment_rms_matches_audioop():
+    """`rms` restates audioop.rms (floor of the root mean square over all interleaved samples): checked against the stdlib."""
+    import warnings
+    import numpy as np
+    from tts_indic_server_f5_amd.audio_prep import PcmSegment
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        import audioop
+    rng = np.random.default_rng(5)
+    x = rng.integers(-20000, 20000, size=(24000, 2)).astype(np.int16)
+    seg = PcmSegment(x, 24000)
+    for a, b in [(0, 1000), (10, 20), (333, 777), (999, 1000)]:
+        fa, fb = int(a * 24.0), int(b * 24.0)
+        assert seg.rms_ms(a, b) == audioop.rms(x[fa:fb].tobytes(), 2)
+    assert len(seg) == 1000 and abs(seg.dbfs_ms(0, 1000) - 20 * np.log10(seg.rms / 32768.0)) < 1e-12
+
+
+def test_detect_and_split_on_silence_known_answers():
+    import numpy as np
+    from tts_indic_server_f5_amd import audio_prep as AP
+    seg = AP.PcmSegment(np.concatenate([_tone(2000), _zeros(1500), _tone(2000)]), 24000)
+    assert AP.detect_silence(seg, min_silence_len=1000, silence_thresh=-50, seek_step=10) == [[2000, 3500]]
+    assert AP.detect_nonsilent(seg, min_silence_len=1000, silence_thresh=-50, seek_step=10) == [[0, 2000], [3500, 5500]]
+    chunks = AP.split_on_silence(seg, min_silence_len=1000, silence_thresh=-50, keep_silence=1000, seek_step=10)
+    assert [len(c) for c in chunks] == [2750, 2750]          # padded ranges overlap -> split at the midpoint (3000 + 2500) // 2
+    assert AP.detect_silence(seg, min_silence_len=2000, silence_thresh=-50, seek_step=10) == []   # pause shorter than the window
+    lead = AP.PcmSegment(np.concatenate([_zeros(300), _tone(1000), _zeros(200)]), 24000)
+    assert AP.detect_leading_silence(lead, silence_threshold=-42) == 300
+    trimmed = AP.remove_silence_edges(lead)
+    assert len(trimmed) in (999, 1000) and abs(int(trimmed.frames[1, 0]) - int(_tone(10)[1])) <= 1
+
+
+def test_preprocess_ref_audio_text(tmp_path):
+    import numpy as np
+    from tts_indic_server_f5_amd import audio_prep as AP
+    from tts_indic_server_f5_amd.infer import load_wav, preprocess_ref_audio_text
+    msgs = []
+    # (1) 20 s with a 1.2 s pause at 8 s: clipped at the pause, edges trimmed, 50 ms of silence appended
+    p1 = tmp_path / "pause.wav"
+    _write_wav(p1, np.concatenate([_tone(8000), _zeros(1200), _tone(10800)]))
+    out, text = preprocess_ref_audio_text(str(p1), "hello there", show_info=msgs.append)
+    w, sr = load_wav(out)
+    assert sr == 24000 and abs(w.shape[-1] - 24 * 8050) <= 48 and text == "hello there. "
+    assert msgs and "(1)" in msgs[0]
+    assert float(w[0, -1200:].abs().max()) == 0.0 and float(w[0, :240].abs().max()) > 0.1
+    # (3) 20 s without any pause: hard cut at 15 s (+ 50 ms)
+    msgs.clear()
+    p2 = tmp_path / "long.wav"
+    _write_wav(p2, _tone(20000))
+    out2, text2 = preprocess_ref_audio_text(str(p2), "Already ends.", show_info=msgs.append)
+    w2, _ = load_wav(out2)
+    assert abs(w2.shape[-1] - 24 * 15050) <= 48 and text2 == "Already ends. " and any("(3)" in m for m in msgs)
+    # short clip with silent edges: only trimmed; CJK full stop and ". " endings are left alone; empty text needs the ASR leaf
+    p3 = tmp_path / "short.wav"
+    _write_wav(p3, np.concatenate([_zeros(400), _tone(3000), _zeros(300)]))
+    out3, text3 = preprocess_ref_audio_text(str(p3), "你好。", show_info=msgs.append)
+    w3, _ = load_wav(out3)
+    assert abs(w3.shape[-1] - 24 * 3050) <= 48 and text3 == "你好。"
+    assert preprocess_ref_audio_text(str(p3), "x. ", show_info=msgs.append)[1] == "x. "
+    import pytest
+    with pytest.raises(NotImplementedError):
+        preprocess_ref_audio_text(str(p3), "  ", show_info=msgs.append)
+    with pytest.raises(ValueError):
+        _write_wav(tmp_path / "lo.wav", _tone(1000, rate=8000), rate=8000)
+        preprocess_ref_audio_text(str(tmp_path / "lo.wav"), "a", show_info=msgs.append)

@@ -1,0 +1,201 @@
+// attn4: attn3 with the two waves of every SIMD in opposite phases ("ping-pong").
+//
+// tools/attn_stamps.py on attn3 (MI355X, N = 1404): per KV tile and wave 600 cycles issuing QK^T, 1 200 cycles of softmax + PV,
+// 1 300 cycles waiting at the ring barrier for the other wave of its SIMD, which is doing exactly the same thing: both waves
+// are in their VALU phase together and in their MFMA phase together, 3 100 cycles per tile.  Here a KV tile is two phases
+// separated by workgroup barriers and waves 4-7 run one phase behind waves 0-3 (details at the loop).
+#pragma once
+#include "attn3.h"
+
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn4_fwd_kernel(const AttnArgs p) {
+    constexpr int NST = 5, STAGE = 16384;
+    __shared__ __attribute__((aligned(16))) char smem[NST * STAGE];
+    const int seq = blockIdx.z, head = blockIdx.y;
+    const int len = p.seq_len[seq], kvlen = p.seq_kvlen[seq], row0 = p.seq_row0[seq];
+    const int q0 = blockIdx.x * 256;
+    if (q0 >= len) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 31, fh = lane >> 5;
+    const int D = p.D;
+    const float LOG2E = 1.4426950408889634f;
+
+    // queries of this wave (rows beyond the sequence stay inside its 128-row padding or the next sequence: finite data,
+    // never stored).  q0 + 255 can exceed the padded rows of the LAST sequence only by < 256 rows: workspace has slack.
+    bf16x8 qf[4];
+    {
+        const __bf16* qrow = p.qk + (size_t)(row0 + q0 + wave * 32 + fr) * (2 * D) + head * 64 + fh * 8;
+#pragma unroll
+        for (int s = 0; s < 4; s++) qf[s] = *reinterpret_cast<const bf16x8*>(qrow + s * 16);
+    }
+    // Retire the Q loads BEFORE the first LDS-DMA is issued: with a DMA in flight hipcc can only wait vmcnt(0) for an
+    // ordinary VGPR load, and it would put that wait inside the KV loop, draining the ring every tile.
+    asm volatile("" ::"v"(qf[0]), "v"(qf[1]), "v"(qf[2]), "v"(qf[3]) : "memory");
+
+    // LDS-DMA: a KV tile is 8 K pieces + 8 V^T pieces of 1 KiB (8 rows x 128 B); wave w moves K piece w and V piece w.
+    // Physical 16-B slot (lane & 7) of row r holds logical chunk (lane & 7) ^ ((r >> 1) & 7)  (same swizzle as attn.h).
+    const int prow = wave * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((prow >> 1) & 7);
+    const char* ksrc = reinterpret_cast<const char*>(p.qk + (size_t)(row0 + prow) * (2 * D) + D + head * 64 + chunk * 8);
+    const char* vsrc = reinterpret_cast<const char*>(p.vt + (size_t)(head * 64 + prow) * p.ldvt + row0 + chunk * 8);
+    const size_t kstep = (size_t)64 * (2 * D) * 2, vstep = 64 * 2;   // bytes per KV tile
+    auto issue_tile = [&](int kt) {
+        char* dst = smem + (kt % NST) * STAGE + wave * 1024;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ksrc + kt * kstep),
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vsrc + kt * vstep),
+                                         (__attribute__((address_space(3))) void*)(dst + 8192), 16, 0, 0);
+    };
+
+    f32x16 oacc[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; dt++)
+#pragma unroll
+        for (int g = 0; g < 16; g++) oacc[dt][g] = 0.0f;
+    float mrun = -1e30f, lrun = 0.0f;
+
+    const int nkt = (kvlen + 63) >> 6;
+#pragma unroll
+    for (int t = 0; t < NST - 1; t++)
+        if (t < nkt) issue_tile(t);
+
+    // S^T tile = K_tile Q^T for the 64 keys of ring stage `st` (8 MFMAs), masked on the last, partial tile
+    auto qk_tile = [&](f32x16 (&s)[2], int kt) {
+        const char* kst = smem + (kt % NST) * STAGE;
+#pragma unroll
+        for (int kh = 0; kh < 2; kh++) {
+#pragma unroll
+            for (int g = 0; g < 16; g++) s[kh][g] = 0.0f;
+#pragma unroll
+            for (int sI = 0; sI < 4; sI++) {
+                bf16x8 kf = *reinterpret_cast<const bf16x8*>(kst + lds_off128(kh * 32 + fr, 2 * sI + fh));
+                s[kh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[sI], s[kh], 0, 0, 0);
+            }
+        }
+        if (kt * 64 + 64 > kvlen) {   // key-padding mask
+#pragma unroll
+            for (int kh = 0; kh < 2; kh++)
+#pragma unroll
+                for (int g = 0; g < 16; g++) {
+                    const int key = kt * 64 + kh * 32 + (g & 3) + 8 * (g >> 2) + 4 * fh;
+                    if (key >= kvlen) s[kh][g] = -1e30f;
+                }
+        }
+    };
+
+    typedef __attribute__((ext_vector_type(2))) float f32x2;
+    // V phase: online softmax of one score tile -> P as four bf16 MFMA operands (packed fp32 VALU ops: two scores per instruction)
+    bf16x8 pf[2][2];
+    auto softmax = [&](f32x16 (&sacc)[2]) {
+        float mloc = sacc[0][0];
+#pragma unroll
+        for (int kh = 0; kh < 2; kh++)
+#pragma unroll
+            for (int g = 0; g < 16; g++) mloc = fmaxf(mloc, sacc[kh][g]);
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        const float mnew = fmaxf(mrun, mloc);
+        const bool moved = mnew != mrun;
+        const float alpha = __builtin_amdgcn_exp2f((mrun - mnew) * LOG2E);
+        mrun = mnew;
+        const f32x2 msc2 = {-mnew * LOG2E, -mnew * LOG2E}, l2e2 = {LOG2E, LOG2E};
+        f32x2 rs2 = {0.0f, 0.0f};
+#pragma unroll
+        for (int kh = 0; kh < 2; kh++)
+#pragma unroll
+            for (int g = 0; g < 16; g += 2) {
+                f32x2 t = {sacc[kh][g], sacc[kh][g + 1]};
+                t = __builtin_elementwise_fma(t, l2e2, msc2);
+                t[0] = __builtin_amdgcn_exp2f(t[0]);
+                t[1] = __builtin_amdgcn_exp2f(t[1]);
+                rs2 += t;
+                pf[kh][g >> 3][g & 7] = (__bf16)t[0];
+                pf[kh][g >> 3][(g & 7) + 1] = (__bf16)t[1];
+            }
+        lrun = lrun * alpha + (rs2[0] + rs2[1]);
+        if (__any(moved)) {   // wave-uniform; alpha == 1 exactly for every query whose maximum did not move
+#pragma unroll
+            for (int dt = 0; dt < 2; dt++)
+#pragma unroll
+                for (int g = 0; g < 16; g++) oacc[dt][g] *= alpha;
+        }
+    };
+    // M phase, second half: O^T += V^T P^T for the tile whose P is in pf (8 MFMAs)
+    auto pv_tile = [&](int kt) {
+        const char* vst = smem + (kt % NST) * STAGE + 8192;
+#pragma unroll
+        for (int kh = 0; kh < 2; kh++) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; s2++) {
+#pragma unroll
+                for (int dt = 0; dt < 2; dt++) {
+                    const int row = dt * 32 + fr, c0 = kh * 4 + s2 * 2;
+                    const bf16x4 v0 = *reinterpret_cast<const bf16x4*>(vst + lds_off128(row, c0) + fh * 8);
+                    const bf16x4 v1 = *reinterpret_cast<const bf16x4*>(vst + lds_off128(row, c0 + 1) + fh * 8);
+                    bf16x8 vf;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) { vf[e] = v0[e]; vf[4 + e] = v1[e]; }
+                    oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kh][s2], oacc[dt], 0, 0, 0);
+                }
+            }
+        }
+    };
+    // this wave's DMA pieces of tile j have landed (tiles j + 1, j + 2 may stay in flight)
+    auto wait_tile = [&](int j) {
+        const int newer = min(2, nkt - 1 - j);
+        if (newer >= 2) attn_wait_vmcnt<4>();
+        else if (newer == 1) attn_wait_vmcnt<2>();
+        else attn_wait_vmcnt<0>();
+    };
+
+    // Ping-pong: waves 0-3 (group 0) and waves 4-7 (group 1) sit pairwise on the same SIMDs.  Every KV tile is two phases split by
+    // workgroup barriers -- V (softmax on the VALU) and M (QK^T of the next tile + PV of this one on the matrix pipe) -- and group 1
+    // runs one phase behind group 0, so a SIMD always has one wave in V and one in M instead of both in the same phase.
+    const int grp = wave >> 2;
+    f32x16 sa[2], sb[2];
+    if (nkt >= 4) attn_wait_vmcnt<6>(); else if (nkt == 3) attn_wait_vmcnt<4>(); else if (nkt == 2) attn_wait_vmcnt<2>(); else attn_wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();                    // tile 0 landed
+    qk_tile(sa, 0);
+    if (grp == 1) { wait_tile(1); __builtin_amdgcn_s_barrier(); }   // skew (pairs with group 0's first phase boundary)
+#define A4_STEP(SCUR, SNEXT, KT)                                                                     \
+    {                                                                                                \
+        softmax(SCUR);                                                                               \
+        if (grp == 0) wait_tile((KT) + 1);                                                           \
+        __builtin_amdgcn_s_barrier();                /* V | M: group 1 has finished M of tile KT - 1: its stage is free */ \
+        if ((KT) + NST - 1 < nkt) issue_tile((KT) + NST - 1);                                        \
+        if ((KT) + 1 < nkt) qk_tile(SNEXT, (KT) + 1);                                                \
+        pv_tile(KT);                                                                                 \
+        if (grp == 1) wait_tile((KT) + 2);                                                           \
+        __builtin_amdgcn_s_barrier();                /* M | V */                                     \
+    }
+    for (int kt = 0; kt < nkt; kt += 2) {
+        A4_STEP(sa, sb, kt);
+        if (kt + 1 >= nkt) break;
+        A4_STEP(sb, sa, kt + 1);
+    }
+#undef A4_STEP
+    if (grp == 0) __builtin_amdgcn_s_barrier();      // balances group 1's skew barrier
+
+    const float ltot = lrun + __shfl_xor(lrun, 32, 64);
+    const float inv = 1.0f / ltot;
+    const int q = q0 + wave * 32 + fr;
+    if (q < len) {
+        const size_t obase = (size_t)(row0 + q) * D + head * 64;
+#pragma unroll
+        for (int dt = 0; dt < 2; dt++)
+#pragma unroll
+            for (int a = 0; a < 4; a++) {
+                bf16x4 hi4, lo4;
+                float ov[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) ov[e] = oacc[dt][a * 4 + e] * inv;
+                const int d = dt * 32 + 8 * a + 4 * fh;
+                if (p.f16_out) {
+                    store_f16x4(p.out_hi + obase + d, ov);
+                    continue;
+                }
+                split_bf16x4(ov, hi4, lo4);
+                *reinterpret_cast<bf16x4*>(p.out_hi + obase + d) = hi4;
+                if (p.out_lo) *reinterpret_cast<bf16x4*>(p.out_lo + obase + d) = lo4;
+            }
+    }
+}

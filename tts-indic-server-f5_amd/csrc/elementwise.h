@@ -97,11 +97,22 @@ __global__ __launch_bounds__(256) void grn_stats_kernel(const float* y, int ldy,
     const int seq = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
     const int r0 = seq_row0[seq], n = seq_len[seq];
-    float acc = 0.0f;
-    for (int r = 0; r < n; r++) {
-        const float t = y[(size_t)(r0 + r) * ldy + c];
-        acc += t * t;
+    // 8 independent loads in flight per thread: the serial one-row-at-a-time loop was pure load latency (327 us at N = 1404)
+    float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const float* col = y + (size_t)r0 * ldy + c;
+    int r = 0;
+    for (; r + 8 <= n; r += 8) {
+        float t[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) t[u] = col[(size_t)(r + u) * ldy];
+#pragma unroll
+        for (int u = 0; u < 8; u++) a8[u] += t[u] * t[u];
     }
+    for (; r < n; r++) {
+        const float t = col[(size_t)r * ldy];
+        a8[0] += t * t;
+    }
+    const float acc = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
     gx[(size_t)seq * C + c] = sqrtf(acc);
 }
 

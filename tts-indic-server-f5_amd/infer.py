@@ -8,6 +8,7 @@ Host-side differences, all explicit:
     torchaudio is not part of this image;
   * resampling to 24 kHz restates torchaudio.transforms.Resample (sinc interpolation, Hann window, width 6, rolloff
     0.99; third-party leaf, parity unpinned) on the host, like the reference does before `.to(device)`;
+  * `preprocess_ref_audio_text` (silence clipping of the reference clip, ". " rule) is restated without pydub in `audio_prep.py`;
   * `convert_char_to_pinyin` (jieba + pypinyin) is replaced by `text_to_tokens`, which reproduces the reference's
     behaviour for text without CJK characters (per-character tokens, the same punctuation translation table)
     and rejects CJK input instead of silently mis-tokenising it.
@@ -19,6 +20,8 @@ import wave as _wave
 
 import numpy as np
 import torch
+
+from .audio_prep import preprocess_ref_audio_text, remove_silence_edges  # noqa: F401  (F/infer/utils_infer.py:263-350)
 
 # ----------------------------------------- F/infer/utils_infer.py:40-53
 target_sample_rate = 24000
