@@ -60,3 +60,41 @@ def test_infer_process_matches_oracle_pipeline(amp):
     print(f"[parity] e2e amp={amp}: mel rms err {mel_rms:.3e}  wave max err {wav_max:.3e}  wave rms {np.sqrt(np.mean(w_ref ** 2)):.3e}  n={len(w_ref)}")
     assert mel_rms < 1e-3
     assert wav_max < 1e-4   # north_star waveform bound, end to end (vocoder-only parity is 1e-6)
+
+
+def test_speech_endpoint_on_hip_path(tmp_path):
+    """POST /v1/audio/speech (serve.py, S/routes/speech.py:19-41) through TTSManager -> preprocess_ref_audio_text -> infer_process on
+    the HIP objects: the WAV in the response is the 16-bit quantisation of the direct infer_process output, and that output matches
+    the CPU oracle driven by the same glue."""
+    import io
+    import wave
+    from fastapi.testclient import TestClient
+    from tts_indic_server_f5_amd import serve
+    from tts_indic_server_f5_amd.model import DiTArch, F5HipModel
+    from tts_indic_server_f5_amd.vocoder import F5HipVocos
+    sd, vsd = synth.dit_state_dict(**ARCH), synth.vocos_state_dict()
+    x = np.concatenate([np.zeros(4800), synth.ref_audio(24000 * 2, amp=0.12)[0].numpy(), np.zeros(2400)])
+    prompt = tmp_path / "voice.wav"
+    with wave.open(str(prompt), "wb") as f:
+        f.setnchannels(1); f.setsampwidth(2); f.setframerate(24000)
+        f.writeframes(np.clip(np.rint(x * 32768), -32768, 32767).astype("<i2").tobytes())
+    reg = serve.VoiceRegistry()
+    reg.add("KAN_F (Happy)", str(prompt), "Some call me nature")
+    mgr = serve.TTSManager(nfe_step=8).load(F5HipModel(DiTArch(**ARCH), sd, vocab_char_map=VOCAB), F5HipVocos(vsd))
+    client = TestClient(serve.create_app(mgr, reg))
+    text = "I have been a silent spectator. Always remember, I endure."
+    torch.manual_seed(7)
+    r = client.post("/v1/audio/speech", json={"text": text})
+    assert r.status_code == 200 and r.headers["content-type"] == "audio/wav"
+    with wave.open(io.BytesIO(r.content), "rb") as f:
+        assert f.getframerate() == 24000
+        pcm = np.frombuffer(f.readframes(f.getnframes()), dtype="<i2")
+    wav_path, ref_text = infer.preprocess_ref_audio_text(str(prompt), "Some call me nature", show_info=lambda *_: None)
+    assert ref_text == "Some call me nature. "
+    kw = dict(nfe_step=8, cfg_strength=2.0, sway_sampling_coef=-1.0, show_info=lambda *_: None)
+    torch.manual_seed(7)
+    w_ref, _, _ = infer.infer_process(wav_path, ref_text, text, OracleModel(sd), OracleVocoder(vsd), **kw)
+    assert len(pcm) == len(w_ref)
+    err = float(np.max(np.abs(pcm.astype(np.float64) / 32768.0 - w_ref)))
+    print(f"[parity] /v1/audio/speech vs oracle pipeline: max err {err:.3e} (16-bit step 3.1e-5), n={len(pcm)}")
+    assert err < 1e-4 + 1.0 / 32768
