@@ -65,7 +65,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             __builtin_amdgcn_s_barrier();
             if (kt + NST - 1 < nk && ABL != 1) issue_tile(kt + NST - 1);
         }
-        __syncthreads();   // pairs with the workgroup barrier at the top of gemm_epilogue (consumers)
+        if constexpr (ABL == 0) {
+            // the producers are idle now: they take the lower halves of the consumers' epilogue slabs (gemm_epilogue.h)
+            const int cw = pw, cwm = cw >> 1, cwn = cw & 1;
+            gemm_epilogue8_producer<EPI>(p, reinterpret_cast<const float*>(smem) + cw * 4096, m0 + cwm * 64, n0 + cwn * 64, n0, lane);
+        } else {
+            __syncthreads();   // pairs with the workgroup barrier at the top of gemm_epilogue (consumers)
+        }
         return;
     }
 
@@ -135,7 +141,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     G3_STAMP(2);
     unsigned long long epi_dbg[4] = {0, 0, 0, 0};
-    gemm_epilogue<EPI, TM, TN>(p, acc, reinterpret_cast<float*>(smem) + wave * (TM * TN * 1024), m0 + wm * 64, n0 + wn * 64, n0, lane, ABL == 3 ? epi_dbg : nullptr);
+    if constexpr (ABL == 0) gemm_epilogue8_consumer<EPI>(p, acc, reinterpret_cast<float*>(smem) + wave * 4096, m0 + wm * 64, n0 + wn * 64, n0, lane);
+    else gemm_epilogue<EPI, TM, TN>(p, acc, reinterpret_cast<float*>(smem) + wave * (TM * TN * 1024), m0 + wm * 64, n0 + wn * 64, n0, lane, ABL == 3 ? epi_dbg : nullptr);
     G3_STAMP(3);
 #undef G3_STAMP
     if constexpr (ABL == 3) {

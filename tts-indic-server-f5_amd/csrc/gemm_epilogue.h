@@ -263,3 +263,63 @@ F5_DEVICE void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[TM][TN], float* sl
     if (dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); EPI_STAMP(3); }   // drain of the outstanding stores
 #undef EPI_STAMP
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Eight-wave epilogue of the warp-specialised kernel (gemm3.h): the four consumer waves stage their 64 x 64 accumulators in
+// LDS as before, then the four producer waves -- idle once the k-loop is over -- take the lower 32 rows of each slab, so the
+// row phase (bias / activation / split / residual, the VALU-bound part) runs on two waves per SIMD instead of one.
+// Barrier protocol (every wave of the workgroup, in this order): A = k-loop stages dead, B = slabs complete.  The V block of the
+// QKV projection is stored transposed straight from the accumulators by the consumers alone (n_blk is workgroup-uniform).
+template <int EPI>
+F5_DEVICE void gemm_epilogue_rows32(const GemmArgs& p, const float* slab_half, int m_base, int n_wave, int lane) {
+    if (EPI == EPI_GENERIC) {
+        switch (p.act) {
+            case ACT_GELU_TANH: epi_generic_rows<ACT_GELU_TANH, 64, 32>(p, slab_half, m_base, n_wave, lane); break;
+            case ACT_GELU_ERF: epi_generic_rows<ACT_GELU_ERF, 64, 32>(p, slab_half, m_base, n_wave, lane); break;
+            case ACT_MISH: epi_generic_rows<ACT_MISH, 64, 32>(p, slab_half, m_base, n_wave, lane); break;
+            case ACT_SILU: epi_generic_rows<ACT_SILU, 64, 32>(p, slab_half, m_base, n_wave, lane); break;
+            default: epi_generic_rows<ACT_NONE, 64, 32>(p, slab_half, m_base, n_wave, lane); break;
+        }
+    } else {
+        epi_qk_rows<64, 32>(p, slab_half, m_base, n_wave, lane);
+    }
+}
+
+template <int EPI>
+F5_DEVICE void gemm_epilogue8_consumer(const GemmArgs& p, f32x16 (&acc)[2][2], float* slab, int m_wave, int n_wave, int n_blk, int lane) {
+    const int fr = lane & 31, fh = lane >> 5;
+    __syncthreads();                                   // A
+    if (EPI == EPI_QKV && n_blk >= 2 * p.D) {
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const int nd = n_wave - 2 * p.D + j * 32 + fr;
+                const float bv = p.bias[n_wave + j * 32 + fr];
+#pragma unroll
+                for (int a4 = 0; a4 < 4; a4++) {
+                    bf16x4 pk;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) pk[e] = (__bf16)(acc[i][j][a4 * 4 + e] + bv);
+                    *reinterpret_cast<bf16x4*>(p.vt + (size_t)nd * p.ldvt + m_wave + i * 32 + 8 * a4 + 4 * fh) = pk;
+                }
+            }
+        return;                                        // (no barrier B for V blocks: the producers skip it too)
+    }
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int g = 0; g < 16; g++) slab[(i * 32 + (g & 3) + 8 * (g >> 2) + 4 * fh) * 64 + j * 32 + fr] = acc[i][j][g];
+    __syncthreads();                                   // B
+    gemm_epilogue_rows32<EPI>(p, slab, m_wave, n_wave, lane);
+}
+
+template <int EPI>
+F5_DEVICE void gemm_epilogue8_producer(const GemmArgs& p, const float* slab_of_consumer, int m_wave, int n_wave, int n_blk, int lane) {
+    __syncthreads();                                   // A
+    if (EPI == EPI_QKV && n_blk >= 2 * p.D) return;
+    __syncthreads();                                   // B
+    gemm_epilogue_rows32<EPI>(p, slab_of_consumer + 32 * 64, m_wave + 32, n_wave, lane);
+}
