@@ -71,6 +71,9 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise F5HipError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                              "(this package has no CPU fallback)")
+        # torch first: its wheel bundles the HIP runtime (same soname as /opt/rocm's).  If libf5hip.so is the first to pull in a
+        # libamdhip64, the process ends up with the other copy and hipGetDeviceCount() fails inside the library.
+        import torch  # noqa: F401
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(l, name)
