@@ -1,4 +1,6 @@
-// gemm3: warp-specialised split-bf16 MFMA GEMM for gfx950 (128 x 128 x 32 tiles, one 512-thread workgroup per CU).
+// gemm3: warp-specialised MFMA GEMM for gfx950 (128 x 128 x 32 tiles, 512-thread workgroups) -- the production GEMM of the path.
+// Operand precision PREC (template NSPLIT): 1 = bf16, 2 = split bf16 (hi + lo planes, 3 MFMAs per k-step), 3 = fp16 (one plane).
+// One plane: 4 x 16 KiB ring, two workgroups per CU; split bf16: 4 x 32 KiB ring, one workgroup per CU.
 //
 // In-kernel s_memtime stamps of gemm.h (tools/gemm_stamps.py, profiles/) show where a k-step of a lone workgroup goes:
 // 543 cycles ISSUING its 8 global loads per wave (the CU's texture-address path moves ~60 B/clk of these 64-byte row
@@ -7,7 +9,8 @@
 // different waves:
 //   waves 4-7 (producers): LDS-DMA (global_load_lds_dwordx4) of 8 one-KiB pieces per k-tile each, 3 tiles ahead in a
 //                          4 x 32 KiB ring, counted s_waitcnt vmcnt so only the oldest tile is retired per step;
-//   waves 0-3 (consumers): ds_read_b128 fragments + v_mfma_f32_32x32x16_bf16 only (64 x 64 per wave), then the epilogue.
+//   waves 0-3 (consumers): ds_read_b128 fragments + v_mfma_f32_32x32x16_{bf16,f16} only (64 x 64 per wave);
+//   epilogue: all eight waves (gemm_epilogue.h: the producers take half of every consumer's staged tile).
 // One raw s_barrier per k-tile joins both groups: "tile kt has landed" for the consumers, "tile kt-1 is consumed" for
 // the producers, which then refill that stage.  Same LDS image / swizzle / epilogue as gemm2.h.
 #pragma once
