@@ -63,6 +63,10 @@ extern "C" int f5hip_debug_gemm_bench(int32_t M, int32_t N, int32_t K, int32_t p
         else if (variant == 30) e = planes == 2 ? launch_gemm3_t<2, EPI_GENERIC>(a, M, N, 0) : launch_gemm3_t<1, EPI_GENERIC>(a, M, N, 0);
         else if (variant == 31) e = launch_gemm3_t<2, EPI_GENERIC, 1>(a, M, N, 0);
         else if (variant == 32) e = launch_gemm3_t<2, EPI_GENERIC, 2>(a, M, N, 0);
+        else if (variant == 33) e = launch_gemm3_t<1, EPI_GENERIC, 1>(a, M, N, 0);
+        else if (variant == 34) e = launch_gemm3_t<1, EPI_GENERIC, 2>(a, M, N, 0);
+        else if (variant == 35) e = launch_gemm3_t<1, EPI_GENERIC, 4>(a, M, N, 0);
+        else if (variant == 36) e = launch_gemm3_t<2, EPI_GENERIC, 4>(a, M, N, 0);
         else if (variant == 21) e = planes == 2 ? launch_gemm2_t<2, 256, 128, EPI_GENERIC>(a, M, N, 0) : launch_gemm2_t<1, 256, 128, EPI_GENERIC>(a, M, N, 0);
         else if (planes == 2 && bn == 128) {
             if (variant == 0) e = launch_gemm_t<2, 128, false, EPI_GENERIC, 0>(a, M, N, 0);

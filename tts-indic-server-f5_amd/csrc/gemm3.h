@@ -16,7 +16,8 @@
 #pragma once
 #include "gemm2.h"
 
-// ABL (diagnostics only): 0 = normal, 1 = producers issue no DMA (consumers read whatever is in LDS), 2 = consumers skip the MFMAs
+// ABL (diagnostics only): 0 = normal, 1 = producers issue no DMA (consumers read whatever is in LDS), 2 = consumers skip the MFMAs,
+// 4 = consumers skip the MFMAs AND the producers re-fetch k-tile 0 every step (cache-hot addresses: the DMA issue rate alone)
 template <int NSPLIT, int EPI, int ABL = 0>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm3_kernel(const GemmArgs p) {
     constexpr int NPL = NSPLIT == 2 ? 2 : 1;   // NSPLIT = operand precision: 1 bf16, 2 split bf16 (3 MFMAs), 3 fp16
@@ -54,7 +55,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             char* dst = smem + (kt % NST) * STAGE + pw * (P * 1024);
 #pragma unroll
             for (int j = 0; j < P; j++)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc[j] + (size_t)kt * 64),
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc[j] + (size_t)(ABL == 4 ? 0 : kt) * 64),
                                                  (__attribute__((address_space(3))) void*)(dst + j * 1024), 16, 0, 0);
         };
 #pragma unroll
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
     };
     auto mfma_frags = [&](int buf) {
-        if constexpr (ABL == 2) {
+        if constexpr (ABL == 2 || ABL == 4) {
             asm volatile("" :: "v"(fa[buf][0][0]), "v"(fb[buf][0][0]), "v"(fa[buf][NPL - 1][TM - 1]), "v"(fb[buf][NPL - 1][TN - 1]));
             return;
         }
