@@ -177,3 +177,22 @@ def test_ragged_batch_is_per_item_batch1(tiny_model):
                           edit_mask=em, keep_trajectory=False)
     got, _ = tiny_model.sample(cond[:1], text[:1], 64, steps=5, cfg_strength=0.0, sway_sampling_coef=None, y0=y0[0][None, :64], edit_mask=em)
     assert _report("edit_mask cfg0", got, ref) < 1e-3
+
+
+def test_argument_errors_are_reported_not_faulted(tiny_model):
+    """Error behaviour at the boundary (the reference raises from nn.Embedding / tensor ops; the C ABI returns an error code and a
+    message, and never launches on bad shapes): token id outside the vocabulary, duration beyond max_duration's hard cap, empty batch."""
+    from tts_indic_server_f5_amd._lib import F5HipError
+    g = torch.Generator().manual_seed(3)
+    cond = torch.randn(1, 10, 100, generator=g)
+    good = torch.randint(0, 40, (1, 12), generator=g)
+    out, _ = tiny_model.sample(cond, good, 24, steps=2, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=1)
+    assert out.shape == (1, 24, 100) and torch.isfinite(out).all()
+    bad = good.clone(); bad[0, 3] = 40          # vocabulary is 0..39 (+ the filler row)
+    with pytest.raises(F5HipError, match="outside the vocabulary"):
+        tiny_model.sample(cond, bad, 24, steps=2, cfg_strength=2.0, seed=1)
+    with pytest.raises(F5HipError):
+        tiny_model.transformer_forward(torch.zeros(1, 5000, 100), torch.zeros(1, 5000, 100), good, 0.5, False, False)
+    # the handle is still usable after an error
+    out2, _ = tiny_model.sample(cond, good, 24, steps=2, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=1)
+    assert torch.equal(out, out2)

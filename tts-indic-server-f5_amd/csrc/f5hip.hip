@@ -358,6 +358,8 @@ static int setup_sequences(f5hip_dit* m, const std::vector<SeqDesc>& seqs, int n
             row_start[r] = r0 + extra; row_end[r] = r0 + extra + q.len; row_seq[r] = s;
             int tok = 0;
             if (!q.drop_text && i < nt_max) tok = text[(size_t)q.text_row * nt_max + i] + 1;   // -1 pad -> filler 0
+            // nn.Embedding raises IndexError on an id outside the table; here it would be an out-of-bounds read on the GPU
+            if (tok < 0 || tok > m->cfg.text_num_embeds) return fail(-1, "text token %d of sequence %d is outside the vocabulary (0..%d)", tok - 1, s, m->cfg.text_num_embeds - 1);
             row_token[r] = tok;
             row_frame[r] = q.frame0 + i;
             const bool is_c = frame_is_cond ? frame_is_cond[q.frame0 + i] != 0 : true;
