@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libf5hip.so")
 SOURCES = ["f5hip.hip"]
-HEADERS = ["common.h", "gemm.h", "gemm2.h", "gemm3.h", "gemm4.h", "gemm_epilogue.h", "attn.h", "attn2.h", "attn3.h", "attn4.h", "debug_bench.h", "elementwise.h", "host_util.h", "vocos.h", "bigvgan.h",
+HEADERS = ["common.h", "gemm.h", "gemm2.h", "gemm3.h", "gemm4.h", "gemm_epilogue.h", "attn.h", "attn2.h", "attn3.h", "debug_bench.h", "elementwise.h", "host_util.h", "vocos.h", "bigvgan.h",
            os.path.join("..", "..", "include", "f5hip.h")]
 
 

@@ -14,7 +14,6 @@
 #include "attn.h"
 #include "attn2.h"
 #include "attn3.h"
-#include "attn4.h"
 #include "common.h"
 #include "elementwise.h"
 #include "gemm.h"
@@ -579,8 +578,7 @@ static int launch_attention(f5hip_dit* m, hipStream_t st) {
     prof_begin(PROF_ATTN, st);
     if (attn_impl == 1) hipLaunchKernelGGL(attn_fwd_kernel, dim3((m->max_len + 127) / 128, c.heads, m->n_seq), dim3(256), 0, st, at);
     else if (attn_impl == 2) hipLaunchKernelGGL(attn2_fwd_kernel, dim3((m->max_len + 255) / 256, c.heads, m->n_seq), dim3(512), 0, st, at);
-    else if (attn_impl == 3) hipLaunchKernelGGL(attn3_fwd_kernel, dim3((m->max_len + 255) / 256, c.heads, m->n_seq), dim3(512), 0, st, at);
-    else hipLaunchKernelGGL(attn4_fwd_kernel, dim3((m->max_len + 255) / 256, c.heads, m->n_seq), dim3(512), 0, st, at);
+    else hipLaunchKernelGGL(attn3_fwd_kernel, dim3((m->max_len + 255) / 256, c.heads, m->n_seq), dim3(512), 0, st, at);
     prof_end(PROF_ATTN, st);
     CKL("attention");
     return 0;
