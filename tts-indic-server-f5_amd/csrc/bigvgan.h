@@ -64,7 +64,10 @@ __global__ __launch_bounds__(256) void aa_snake_kernel(const float* x, int ldx, 
 #pragma unroll
         for (int q = 0; q < 6; q++) u += xs[base + q][cl] * f[11 - odd - 2 * q];
         u *= 2.0f;
-        const float sn = sinf(u * ea);
+        // sin on the hardware unit (v_sin_f32 takes revolutions): fp32 range reduction r = a / 2pi - rint(a / 2pi) keeps |a| < ~1e3 rad
+        // within ~1e-5 rad, far inside the 1e-4 waveform bound; libm sinf was ~half of this kernel's time
+        const float rev = u * ea * 0.15915494309189535f;
+        const float sn = __builtin_amdgcn_sinf(rev - rintf(rev));
         as[r][cl] = u + ib * sn * sn;
     }
     __syncthreads();
