@@ -196,3 +196,17 @@ def test_argument_errors_are_reported_not_faulted(tiny_model):
     # the handle is still usable after an error
     out2, _ = tiny_model.sample(cond, good, 24, steps=2, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=1)
     assert torch.equal(out, out2)
+
+
+def test_batch_of_copies_equals_single(base_model):
+    """Size-independent property at the batch-mode shapes (M = 8 x 1408 rows: the wide-tile GEMM path): a batch of identical utterances
+    with identical noise gives, item by item, the batch-1 result (only the fp32 summation order of the GEMM tiles may differ)."""
+    gc = torch.Generator().manual_seed(14)
+    cond = torch.randn(1, 469, 100, generator=gc)
+    text = synth.text_ids()
+    y0 = synth.noise(1404, 0)[None]
+    one, _ = base_model.sample(cond, text, 1404, steps=2, cfg_strength=2.0, sway_sampling_coef=-1.0, y0=y0)
+    four, _ = base_model.sample(cond.expand(4, -1, -1), text.expand(4, -1), 1404, steps=2, cfg_strength=2.0, sway_sampling_coef=-1.0,
+                                y0=y0.expand(4, -1, -1))
+    for i in range(4):
+        assert _report(f"batch-of-copies item {i}", four[i], one[0]) < 2e-5

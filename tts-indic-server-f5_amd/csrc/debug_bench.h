@@ -63,6 +63,7 @@ extern "C" int f5hip_debug_gemm_bench(int32_t M, int32_t N, int32_t K, int32_t p
         else if (variant == 30) e = planes == 2 ? launch_gemm3_t<2, EPI_GENERIC>(a, M, N, 0) : launch_gemm3_t<1, EPI_GENERIC>(a, M, N, 0);
         else if (variant == 31) e = launch_gemm3_t<2, EPI_GENERIC, 1>(a, M, N, 0);
         else if (variant == 32) e = launch_gemm3_t<2, EPI_GENERIC, 2>(a, M, N, 0);
+        else if (variant == 37) e = launch_gemm3_t<1, EPI_GENERIC, 0, 256>(a, M, N, 0);
         else if (variant == 33) e = launch_gemm3_t<1, EPI_GENERIC, 1>(a, M, N, 0);
         else if (variant == 34) e = launch_gemm3_t<1, EPI_GENERIC, 2>(a, M, N, 0);
         else if (variant == 35) e = launch_gemm3_t<1, EPI_GENERIC, 4>(a, M, N, 0);
@@ -120,5 +121,66 @@ extern "C" int f5hip_debug_attn_stamps(int32_t n, int32_t heads, int32_t iters, 
     hipError_t e = hipGetLastError();
     for (void* p : {(void*)f, (void*)qk, (void*)vt, (void*)oh, (void*)ol, (void*)meta, (void*)dbg, (void*)lo_tmp}) hipFree(p);
     if (e != hipSuccess) return fail(-7, "attn stamps: %s", hipGetErrorString(e));
+    return 0;
+}
+
+// one-plane 128 x 128 vs 128 x 256 tile on the same operands: max |difference| and max |value| of the outputs.
+// mode 0: bias + GELU -> fp32;  1: bias + GELU -> one fp16 plane;  2: QKV epilogue (N = 3 D: rotary q | k bf16 rows, V transposed)
+extern "C" int f5hip_debug_gemm_wide_check(int32_t M, int32_t N, int32_t K, int32_t mode, double* max_diff, double* max_abs) {
+    const bool f16 = mode >= 10;   // mode + 10: fp16 operands (PREC 3) instead of bf16
+    if (f16) mode -= 10;
+    if (M % 128 || N % 256 || K % 32 || (mode == 2 && N % 768)) return fail(-1, "wide_check: bad shape");
+    const int D = N / 3;
+    float *fa = nullptr, *fw = nullptr, *bias = nullptr, *rc = nullptr; Plane2 A; PackedW W; int* pos = nullptr;
+    size_t na = (size_t)M * K, nw = (size_t)N * K, no = (size_t)M * N;
+    char* o[2] = {nullptr, nullptr};
+    if (hipMalloc(&fa, na * 4) || hipMalloc(&fw, nw * 4) || hipMalloc(&o[0], no * 4) || hipMalloc(&o[1], no * 4) || hipMalloc(&bias, N * 4) ||
+        hipMalloc(&A.hi, na * 2) || hipMalloc(&A.lo, na * 2) || hipMalloc(&W.hi, nw * 2) || hipMalloc(&W.lo, nw * 2) || hipMalloc(&rc, 4096 * 32 * 4) ||
+        hipMalloc(&pos, M * 4)) return fail(-5, "wide_check: hipMalloc");
+    hipLaunchKernelGGL(fill_pattern_kernel, dim3((na + 255) / 256), dim3(256), 0, 0, fa, na, 1u);
+    hipLaunchKernelGGL(fill_pattern_kernel, dim3((nw + 255) / 256), dim3(256), 0, 0, fw, nw, 2u);
+    hipLaunchKernelGGL(fill_pattern_kernel, dim3((N + 255) / 256), dim3(256), 0, 0, bias, (size_t)N, 3u);
+    hipLaunchKernelGGL(fill_pattern_kernel, dim3(4096 * 32 / 256), dim3(256), 0, 0, rc, (size_t)4096 * 32, 4u);
+    std::vector<int> hpos(M);
+    for (int i = 0; i < M; i++) hpos[i] = i % 1404;
+    hipMemcpy(pos, hpos.data(), M * 4, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(M), dim3(256), 0, 0, fa, M, K, K, A.hi, f16 ? (__bf16*)nullptr : A.lo, K);
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(N), dim3(256), 0, 0, fw, N, K, K, W.hi, f16 ? (__bf16*)nullptr : W.lo, K);
+    W.n = N; W.k = K; W.n_pad = N; W.k_pad = K; W.ld = K; W.bias = bias;
+    hipError_t e = hipSuccess;
+    for (int v = 0; v < 2 && e == hipSuccess; v++) {
+        hipMemset(o[v], 0, no * 4);
+        GemmArgs a = gemm_base(A, K, W, M);
+        if (mode == 2) {
+            a.D = D; a.row_pos = pos; a.rope_cos = rc; a.rope_sin = rc + 64; a.qk = (__bf16*)o[v]; a.vt = (__bf16*)(o[v] + (size_t)M * 2 * D * 2); a.ldvt = M;
+            if (f16) e = v == 0 ? launch_gemm3_t<3, EPI_QKV>(a, M, N, 0) : launch_gemm3_t<3, EPI_QKV, 0, 256>(a, M, N, 0);
+            else e = v == 0 ? launch_gemm3_t<1, EPI_QKV>(a, M, N, 0) : launch_gemm3_t<1, EPI_QKV, 0, 256>(a, M, N, 0);
+        } else {
+            a.act = ACT_GELU_TANH;
+            if (mode == 0) { a.out_f32 = (float*)o[v]; a.ldo = N; }
+            else { a.out_hi = (__bf16*)o[v]; a.ldob = N; a.f16_out = 1; }
+            if (f16) e = v == 0 ? launch_gemm3_t<3, EPI_GENERIC>(a, M, N, 0) : launch_gemm3_t<3, EPI_GENERIC, 0, 256>(a, M, N, 0);
+            else e = v == 0 ? launch_gemm3_t<1, EPI_GENERIC>(a, M, N, 0) : launch_gemm3_t<1, EPI_GENERIC, 0, 256>(a, M, N, 0);
+        }
+    }
+    hipDeviceSynchronize();
+    const size_t nbytes = mode == 0 ? no * 4 : (mode == 1 ? no * 2 : no * 2);
+    std::vector<unsigned char> h1(nbytes), h2(nbytes);
+    hipMemcpy(h1.data(), o[0], nbytes, hipMemcpyDeviceToHost);
+    hipMemcpy(h2.data(), o[1], nbytes, hipMemcpyDeviceToHost);
+    double md = 0, ma = 0; size_t worst = 0, ndiff = 0;
+    if (mode == 0) {
+        const float *x = (const float*)h1.data(), *y = (const float*)h2.data();
+        for (size_t i = 0; i < no; i++) { double d = fabs((double)x[i] - y[i]); if (d > md) { md = d; worst = i; } ma = fmax(ma, fabs((double)x[i])); ndiff += d != 0; }
+    } else {
+        const unsigned short *x = (const unsigned short*)h1.data(), *y = (const unsigned short*)h2.data();
+        for (size_t i = 0; i < no; i++) if (x[i] != y[i]) { if (!ndiff) worst = i; ndiff++; }
+        md = (double)ndiff;
+    }
+    *max_diff = md; *max_abs = ma;
+    fprintf(stderr, "[wide_check] mode %d: %zu differing elements, first / worst at flat index %zu (row %zu col %zu)\n", mode, ndiff, worst, worst / (mode == 2 ? 2 * D : N),
+            worst % (mode == 2 ? 2 * D : N));
+    for (void* q : {(void*)fa, (void*)fw, (void*)o[0], (void*)o[1], (void*)bias, (void*)A.hi, (void*)A.lo, (void*)W.hi, (void*)W.lo, (void*)rc, (void*)pos}) hipFree(q);
+    if (e != hipSuccess) return fail(-7, "wide_check launch: %s", hipGetErrorString(e));
     return 0;
 }

@@ -18,11 +18,13 @@
 
 // ABL (diagnostics only): 0 = normal, 1 = producers issue no DMA (consumers read whatever is in LDS), 2 = consumers skip the MFMAs,
 // 4 = consumers skip the MFMAs AND the producers re-fetch k-tile 0 every step (cache-hot addresses: the DMA issue rate alone)
-template <int NSPLIT, int EPI, int ABL = 0>
+// BN = 256 ("wide"): each consumer wave owns 64 x 128 (4 accumulator tiles across): 25 % fewer operand bytes per FLOP and 16 MFMAs
+// between barriers, for GEMMs whose 128 x 256 tile count fits one round on the CUs (FF1 at one utterance per GPU: 176 tiles).
+template <int NSPLIT, int EPI, int ABL = 0, int BN = 128>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm3_kernel(const GemmArgs p) {
     constexpr int NPL = NSPLIT == 2 ? 2 : 1;   // NSPLIT = operand precision: 1 bf16, 2 split bf16 (3 MFMAs), 3 fp16
     constexpr bool F16 = NSPLIT == 3;
-    constexpr int BM = 128, BN = 128, TM = 2, TN = 2, NST = 4;
+    constexpr int BM = 128, TM = 2, TN = BN / 64, NST = 4;
     constexpr int A_PLANE = BM * 64, B_PLANE = BN * 64, STAGE = NPL * (A_PLANE + B_PLANE);
     constexpr int P = STAGE / 1024 / 4;   // DMA pieces per producer wave per k-tile
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -72,7 +74,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if constexpr (ABL == 0) {
             // the producers are idle now: they take the lower halves of the consumers' epilogue slabs (gemm_epilogue.h)
             const int cw = pw, cwm = cw >> 1, cwn = cw & 1;
-            gemm_epilogue8_producer<EPI>(p, reinterpret_cast<const float*>(smem) + cw * 4096, m0 + cwm * 64, n0 + cwn * 64, n0, lane);
+            gemm_epilogue8_producer<EPI, TN>(p, reinterpret_cast<const float*>(smem) + cw * (64 * 32 * TN), m0 + cwm * 64, n0 + cwn * (32 * TN), n0, lane);
         } else {
             __syncthreads();   // pairs with the workgroup barrier at the top of gemm_epilogue (consumers)
         }
@@ -102,7 +104,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 fa[buf][pl][i] = *reinterpret_cast<const bf16x8*>(st + pl * A_PLANE + lds_off2(wm * 64 + i * 32 + fr, chunk));
 #pragma unroll
             for (int j = 0; j < TN; j++)
-                fb[buf][pl][j] = *reinterpret_cast<const bf16x8*>(st + NPL * A_PLANE + pl * B_PLANE + lds_off2(wn * 64 + j * 32 + fr, chunk));
+                fb[buf][pl][j] = *reinterpret_cast<const bf16x8*>(st + NPL * A_PLANE + pl * B_PLANE + lds_off2(wn * (32 * TN) + j * 32 + fr, chunk));
         }
     };
     auto mfma_frags = [&](int buf) {
@@ -145,8 +147,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     G3_STAMP(2);
     unsigned long long epi_dbg[4] = {0, 0, 0, 0};
-    if constexpr (ABL == 0) gemm_epilogue8_consumer<EPI>(p, acc, reinterpret_cast<float*>(smem) + wave * 4096, m0 + wm * 64, n0 + wn * 64, n0, lane);
-    else gemm_epilogue<EPI, TM, TN>(p, acc, reinterpret_cast<float*>(smem) + wave * (TM * TN * 1024), m0 + wm * 64, n0 + wn * 64, n0, lane, ABL == 3 ? epi_dbg : nullptr);
+    if constexpr (ABL == 0) gemm_epilogue8_consumer<EPI, TN>(p, acc, reinterpret_cast<float*>(smem) + wave * (64 * 32 * TN), m0 + wm * 64, n0 + wn * (32 * TN), n0, lane);
+    else gemm_epilogue<EPI, TM, TN>(p, acc, reinterpret_cast<float*>(smem) + wave * (TM * TN * 1024), m0 + wm * 64, n0 + wn * (32 * TN), n0, lane, ABL == 3 ? epi_dbg : nullptr);
     G3_STAMP(3);
 #undef G3_STAMP
     if constexpr (ABL == 3) {
@@ -157,17 +159,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
-template <int NSPLIT, int EPI, int ABL = 0>
+template <int NSPLIT, int EPI, int ABL = 0, int BN = 128>
 static hipError_t launch_gemm3_t(const GemmArgs& a, int m_pad, int n_pad, hipStream_t st) {
     constexpr int NPL = NSPLIT == 2 ? 2 : 1;
-    constexpr int LDS = 4 * NPL * (128 + 128) * 64 > 65536 ? 4 * NPL * (128 + 128) * 64 : 65536;
+    constexpr int RING = 4 * NPL * (128 + BN) * 64, SLABS = 4 * 64 * (BN / 2) * 4;   // k-loop ring; four 64 x BN/2 fp32 epilogue slabs
+    constexpr int LDS = RING > SLABS ? RING : SLABS;
+    static_assert(LDS <= 160 * 1024, "tile does not fit the LDS");
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm3_kernel<NSPLIT, EPI, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm3_kernel<NSPLIT, EPI, ABL, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    dim3 grid(n_pad / 128, m_pad / 128);
-    hipLaunchKernelGGL((gemm3_kernel<NSPLIT, EPI, ABL>), grid, dim3(512), LDS, st, a);
+    dim3 grid(n_pad / BN, m_pad / 128);
+    hipLaunchKernelGGL((gemm3_kernel<NSPLIT, EPI, ABL, BN>), grid, dim3(512), LDS, st, a);
     return hipGetLastError();
 }

@@ -160,7 +160,7 @@ F5_DEVICE void epi_qk_rows_t(const GemmArgs& p, const float* stg, int m_base, in
     for (int q = 0; q < NQ; q++) {
         cs[q] = make_float2(1.f, 1.f);
         sn[q] = make_float2(0.f, 0.f);
-        if (ROT) {
+        if (ROT && nd < 64) {   // (a wave tile wider than one head -- WN = 128 -- rotates only its lanes inside head 0)
             const int pos = p.row_pos[m_base + q * RPP + r0];
             cs[q] = *reinterpret_cast<const float2*>(p.rope_cos + pos * 32 + (nd >> 1));
             sn[q] = *reinterpret_cast<const float2*>(p.rope_sin + pos * 32 + (nd >> 1));
@@ -270,30 +270,30 @@ F5_DEVICE void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[TM][TN], float* sl
 // row phase (bias / activation / split / residual, the VALU-bound part) runs on two waves per SIMD instead of one.
 // Barrier protocol (every wave of the workgroup, in this order): A = k-loop stages dead, B = slabs complete.  The V block of the
 // QKV projection is stored transposed straight from the accumulators by the consumers alone (n_blk is workgroup-uniform).
-template <int EPI>
+template <int EPI, int WN>
 F5_DEVICE void gemm_epilogue_rows32(const GemmArgs& p, const float* slab_half, int m_base, int n_wave, int lane) {
     if (EPI == EPI_GENERIC) {
         switch (p.act) {
-            case ACT_GELU_TANH: epi_generic_rows<ACT_GELU_TANH, 64, 32>(p, slab_half, m_base, n_wave, lane); break;
-            case ACT_GELU_ERF: epi_generic_rows<ACT_GELU_ERF, 64, 32>(p, slab_half, m_base, n_wave, lane); break;
-            case ACT_MISH: epi_generic_rows<ACT_MISH, 64, 32>(p, slab_half, m_base, n_wave, lane); break;
-            case ACT_SILU: epi_generic_rows<ACT_SILU, 64, 32>(p, slab_half, m_base, n_wave, lane); break;
-            default: epi_generic_rows<ACT_NONE, 64, 32>(p, slab_half, m_base, n_wave, lane); break;
+            case ACT_GELU_TANH: epi_generic_rows<ACT_GELU_TANH, WN, 32>(p, slab_half, m_base, n_wave, lane); break;
+            case ACT_GELU_ERF: epi_generic_rows<ACT_GELU_ERF, WN, 32>(p, slab_half, m_base, n_wave, lane); break;
+            case ACT_MISH: epi_generic_rows<ACT_MISH, WN, 32>(p, slab_half, m_base, n_wave, lane); break;
+            case ACT_SILU: epi_generic_rows<ACT_SILU, WN, 32>(p, slab_half, m_base, n_wave, lane); break;
+            default: epi_generic_rows<ACT_NONE, WN, 32>(p, slab_half, m_base, n_wave, lane); break;
         }
     } else {
-        epi_qk_rows<64, 32>(p, slab_half, m_base, n_wave, lane);
+        epi_qk_rows<WN, 32>(p, slab_half, m_base, n_wave, lane);
     }
 }
 
-template <int EPI>
-F5_DEVICE void gemm_epilogue8_consumer(const GemmArgs& p, f32x16 (&acc)[2][2], float* slab, int m_wave, int n_wave, int n_blk, int lane) {
+template <int EPI, int TN = 2>
+F5_DEVICE void gemm_epilogue8_consumer(const GemmArgs& p, f32x16 (&acc)[2][TN], float* slab, int m_wave, int n_wave, int n_blk, int lane) {
     const int fr = lane & 31, fh = lane >> 5;
     __syncthreads();                                   // A
     if (EPI == EPI_QKV && n_blk >= 2 * p.D) {
 #pragma unroll
         for (int i = 0; i < 2; i++)
 #pragma unroll
-            for (int j = 0; j < 2; j++) {
+            for (int j = 0; j < TN; j++) {
                 const int nd = n_wave - 2 * p.D + j * 32 + fr;
                 const float bv = p.bias[n_wave + j * 32 + fr];
 #pragma unroll
@@ -306,20 +306,21 @@ F5_DEVICE void gemm_epilogue8_consumer(const GemmArgs& p, f32x16 (&acc)[2][2], f
             }
         return;                                        // (no barrier B for V blocks: the producers skip it too)
     }
+    constexpr int WN = 32 * TN;
 #pragma unroll
     for (int i = 0; i < 2; i++)
 #pragma unroll
-        for (int j = 0; j < 2; j++)
+        for (int j = 0; j < TN; j++)
 #pragma unroll
-            for (int g = 0; g < 16; g++) slab[(i * 32 + (g & 3) + 8 * (g >> 2) + 4 * fh) * 64 + j * 32 + fr] = acc[i][j][g];
+            for (int g = 0; g < 16; g++) slab[(i * 32 + (g & 3) + 8 * (g >> 2) + 4 * fh) * WN + j * 32 + fr] = acc[i][j][g];
     __syncthreads();                                   // B
-    gemm_epilogue_rows32<EPI>(p, slab, m_wave, n_wave, lane);
+    gemm_epilogue_rows32<EPI, WN>(p, slab, m_wave, n_wave, lane);
 }
 
-template <int EPI>
+template <int EPI, int TN = 2>
 F5_DEVICE void gemm_epilogue8_producer(const GemmArgs& p, const float* slab_of_consumer, int m_wave, int n_wave, int n_blk, int lane) {
     __syncthreads();                                   // A
     if (EPI == EPI_QKV && n_blk >= 2 * p.D) return;
     __syncthreads();                                   // B
-    gemm_epilogue_rows32<EPI>(p, slab_of_consumer + 32 * 64, m_wave + 32, n_wave, lane);
+    gemm_epilogue_rows32<EPI, 32 * TN>(p, slab_of_consumer + 32 * (32 * TN), m_wave + 32, n_wave, lane);
 }
