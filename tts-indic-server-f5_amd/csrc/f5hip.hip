@@ -427,7 +427,9 @@ static int run_gemm_n(int nsplit, int mp, GemmArgs& a, const PackedW& W, int epi
         // three epilogues, bf16 and fp16) but inside the sampler a batch of copies then differs from the single utterance by 5.6e-4 rms
         // (tests/test_gpu_dit.py::test_batch_of_copies_equals_single) -- unexplained, so not shipped.
         static const bool want_wide = getenv("F5HIP_WIDE") != nullptr;
-        const bool wide = g_gemm_impl == 0 && want_wide && tiles128 >= 1024 && np % 256 == 0;
+        static const bool wide_qkv_only = getenv("F5HIP_WIDE_QKV_ONLY") != nullptr, wide_gen_only = getenv("F5HIP_WIDE_GENERIC_ONLY") != nullptr;
+        static const int wide_min_tiles = getenv("F5HIP_WIDE") ? atoi(getenv("F5HIP_WIDE")) : 0;   // F5HIP_WIDE=<min 128 x 128 tiles>, e.g. 1024
+        const bool wide = g_gemm_impl == 0 && want_wide && tiles128 >= wide_min_tiles && np % 256 == 0 && (wide_qkv_only ? epi == EPI_QKV : true) && (wide_gen_only ? epi != EPI_QKV : true);
         if (wide) e = epi == EPI_QKV ? launch_gemm3_t<3, EPI_QKV, 0, 256>(a, mp, np, st) : launch_gemm3_t<3, EPI_GENERIC, 0, 256>(a, mp, np, st);
         else if (g_gemm_impl == 1) e = epi == EPI_QKV ? launch_gemm_t<3, 128, false, EPI_QKV>(a, mp, np, st) : launch_gemm_t<3, 128, false, EPI_GENERIC>(a, mp, np, st);
         else e = epi == EPI_QKV ? launch_gemm3_t<3, EPI_QKV>(a, mp, np, st) : launch_gemm3_t<3, EPI_GENERIC>(a, mp, np, st);
