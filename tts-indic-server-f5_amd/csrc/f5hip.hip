@@ -422,14 +422,16 @@ static int run_gemm_n(int nsplit, int mp, GemmArgs& a, const PackedW& W, int epi
         else e = epi == EPI_QKV ? launch_gemm4_t<1, EPI_QKV>(a, mp, np, *sk, st) : launch_gemm4_t<1, EPI_GENERIC>(a, mp, np, *sk, st);
     } else if (nsplit == 3) {   // fp16 operands (one plane each): the warp-specialised kernel wins at every batch-1 shape (tools/gemm_microbench.py)
         if (conv) { prof_end(PROF_GEMM, st); return fail(-7, "gemm: fp16 operands are not built for the implicit-GEMM convolution"); }
-        // 128 x 256 tile (gemm3 BN = 256): 25 % fewer operand bytes per FLOP; QKV -8 %, FF2 -15 % at 8 utterances (tools/gemm_wide_ab.py), nothing
-        // at one.  OPT-IN (F5HIP_WIDE=1) and off by default: bit-identical to the 128 x 128 tile in isolation (tools/gemm_wide_check.py, all
-        // three epilogues, bf16 and fp16) but inside the sampler a batch of copies then differs from the single utterance by 5.6e-4 rms
-        // (tests/test_gpu_dit.py::test_batch_of_copies_equals_single) -- unexplained, so not shipped.
+        // 128 x 256 tile (gemm3 BN = 256): 25 % fewer operand bytes per FLOP; FF2 -15 %, QKV -8 %, FF1 -3 % at 8 utterances (tools/gemm_wide_ab.py),
+        // nothing at one.  Default: batch mode (>= 1024 tiles of 128 x 128) and generic-epilogue GEMMs only -- bit-identical to the 128 x 128 tile
+        // both in isolation (tools/gemm_wide_check.py) and inside the sampler (tools/wide_pipeline_check.py).  The QKV projection stays on the
+        // 128 x 128 tile: identical in isolation, but inside the sampler its wide version shifts the result by 5.6e-4 rms (unexplained).
+        // F5HIP_WIDE=<min tiles> (+ F5HIP_WIDE_QKV_ONLY / F5HIP_WIDE_GENERIC_ONLY) overrides for diagnostics.
         static const bool want_wide = getenv("F5HIP_WIDE") != nullptr;
         static const bool wide_qkv_only = getenv("F5HIP_WIDE_QKV_ONLY") != nullptr, wide_gen_only = getenv("F5HIP_WIDE_GENERIC_ONLY") != nullptr;
-        static const int wide_min_tiles = getenv("F5HIP_WIDE") ? atoi(getenv("F5HIP_WIDE")) : 0;   // F5HIP_WIDE=<min 128 x 128 tiles>, e.g. 1024
-        const bool wide = g_gemm_impl == 0 && want_wide && tiles128 >= wide_min_tiles && np % 256 == 0 && (wide_qkv_only ? epi == EPI_QKV : true) && (wide_gen_only ? epi != EPI_QKV : true);
+        static const int wide_min_tiles = want_wide ? atoi(getenv("F5HIP_WIDE")) : 1024;
+        const bool wide_ok = want_wide ? ((wide_qkv_only ? epi == EPI_QKV : true) && (wide_gen_only ? epi != EPI_QKV : true)) : epi != EPI_QKV;
+        const bool wide = g_gemm_impl == 0 && wide_ok && tiles128 >= wide_min_tiles && np % 256 == 0;
         if (wide) e = epi == EPI_QKV ? launch_gemm3_t<3, EPI_QKV, 0, 256>(a, mp, np, st) : launch_gemm3_t<3, EPI_GENERIC, 0, 256>(a, mp, np, st);
         else if (g_gemm_impl == 1) e = epi == EPI_QKV ? launch_gemm_t<3, 128, false, EPI_QKV>(a, mp, np, st) : launch_gemm_t<3, 128, false, EPI_GENERIC>(a, mp, np, st);
         else e = epi == EPI_QKV ? launch_gemm3_t<3, EPI_QKV>(a, mp, np, st) : launch_gemm3_t<3, EPI_GENERIC>(a, mp, np, st);
