@@ -423,14 +423,13 @@ static int run_gemm_n(int nsplit, int mp, GemmArgs& a, const PackedW& W, int epi
     } else if (nsplit == 3) {   // fp16 operands (one plane each): the warp-specialised kernel wins at every batch-1 shape (tools/gemm_microbench.py)
         if (conv) { prof_end(PROF_GEMM, st); return fail(-7, "gemm: fp16 operands are not built for the implicit-GEMM convolution"); }
         // 128 x 256 tile (gemm3 BN = 256): 25 % fewer operand bytes per FLOP; FF2 -15 %, QKV -8 %, FF1 -3 % at 8 utterances (tools/gemm_wide_ab.py),
-        // nothing at one.  Default: batch mode (>= 1024 tiles of 128 x 128) and generic-epilogue GEMMs only -- bit-identical to the 128 x 128 tile
-        // both in isolation (tools/gemm_wide_check.py) and inside the sampler (tools/wide_pipeline_check.py).  The QKV projection stays on the
-        // 128 x 128 tile: identical in isolation, but inside the sampler its wide version shifts the result by 5.6e-4 rms (unexplained).
+        // nothing at one.  Default: batch mode (>= 1024 tiles of 128 x 128).  Bit-identical to the 128 x 128 tile in isolation
+        // (tools/gemm_wide_check.py) and inside the sampler (tests/test_gpu_dit.py::test_batch_of_copies_equals_single).
         // F5HIP_WIDE=<min tiles> (+ F5HIP_WIDE_QKV_ONLY / F5HIP_WIDE_GENERIC_ONLY) overrides for diagnostics.
         static const bool want_wide = getenv("F5HIP_WIDE") != nullptr;
         static const bool wide_qkv_only = getenv("F5HIP_WIDE_QKV_ONLY") != nullptr, wide_gen_only = getenv("F5HIP_WIDE_GENERIC_ONLY") != nullptr;
         static const int wide_min_tiles = want_wide ? atoi(getenv("F5HIP_WIDE")) : 1024;
-        const bool wide_ok = want_wide ? ((wide_qkv_only ? epi == EPI_QKV : true) && (wide_gen_only ? epi != EPI_QKV : true)) : epi != EPI_QKV;
+        const bool wide_ok = (wide_qkv_only ? epi == EPI_QKV : true) && (wide_gen_only ? epi != EPI_QKV : true);
         const bool wide = g_gemm_impl == 0 && wide_ok && tiles128 >= wide_min_tiles && np % 256 == 0;
         if (wide) e = epi == EPI_QKV ? launch_gemm3_t<3, EPI_QKV, 0, 256>(a, mp, np, st) : launch_gemm3_t<3, EPI_GENERIC, 0, 256>(a, mp, np, st);
         else if (g_gemm_impl == 1) e = epi == EPI_QKV ? launch_gemm_t<3, 128, false, EPI_QKV>(a, mp, np, st) : launch_gemm_t<3, 128, false, EPI_GENERIC>(a, mp, np, st);
@@ -689,6 +688,41 @@ static int forward_step(f5hip_dit* m, int ti, int n_blocks, hipStream_t st) {
         GemmArgs q = gemm_base(m->hn, D, m->wqkv[l], M);
         q.D = D; q.row_pos = m->d_row_pos; q.rope_cos = m->rope_cos; q.rope_sin = m->rope_sin; q.qk = m->qk; q.vt = m->vt; q.ldvt = m->M_pad;
         CK(run_gemm(m, q, m->wqkv[l], EPI_QKV, false, 128, st));
+        if (getenv("F5HIP_DUMP_QKV") && l == atoi(getenv("F5HIP_DUMP_QKV")) / 100 && ti == atoi(getenv("F5HIP_DUMP_QKV")) % 100) {   // F5HIP_DUMP_QKV = 100 * layer + step   // diagnostics: checksums of the first QKV projection by column block
+            (void)hipStreamSynchronize(st);
+            std::vector<unsigned short> hq((size_t)M * 2 * D), hv((size_t)D * m->M_pad);
+            (void)hipMemcpy(hq.data(), m->qk, hq.size() * 2, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(hv.data(), m->vt, hv.size() * 2, hipMemcpyDeviceToHost);
+            auto bf = [](unsigned short u) { unsigned v = (unsigned)u << 16; float f; memcpy(&f, &v, 4); return (double)f; };
+            const int edges[6] = {0, 64, 128, 256, 512, D};
+            for (int part = 0; part < 2; part++)
+                for (int e = 0; e < 5; e++) {
+                    double sum = 0, asum = 0;
+                    for (int r = 0; r < M; r++)
+                        for (int c = edges[e]; c < edges[e + 1]; c++) { const double x = bf(hq[(size_t)r * 2 * D + part * D + c]); sum += x; asum += fabs(x); }
+                    fprintf(stderr, "[dump_qkv] %s cols [%d,%d): sum %.6f abs %.6f\n", part ? "K" : "Q", edges[e], edges[e + 1], sum, asum);
+                }
+            for (int e = 0; e < 5; e++) {
+                double sum = 0, asum = 0;
+                for (int c = edges[e]; c < edges[e + 1]; c++)
+                    for (int r = 0; r < M; r++) { const double x = bf(hv[(size_t)c * m->M_pad + r]); sum += x; asum += fabs(x); }
+                fprintf(stderr, "[dump_qkv] V rows [%d,%d): sum %.6f abs %.6f\n", edges[e], edges[e + 1], sum, asum);
+            }
+            // side effects: word checksums of every other workspace buffer (an out-of-bounds store of the projection would show here)
+            struct { const char* name; const void* p; size_t bytes; } bufs[] = {
+                {"h", m->h, (size_t)M * D * 4}, {"h0", m->h0, (size_t)M * D * 4}, {"ce", m->ce, (size_t)M * D * 4}, {"pred", m->pred, (size_t)M * 128 * 4},
+                {"mod", m->mod, (size_t)128 * m->n_adaln * 4}, {"hn.hi", m->hn.hi, (size_t)M * D * 2}, {"hn.lo", m->hn.lo, (size_t)M * D * 2},
+                {"c1.hi", m->c1.hi, (size_t)M * D * 2}, {"ao.hi", m->ao.hi, (size_t)M * D * 2}, {"ao.lo", m->ao.lo, (size_t)M * D * 2},
+                {"ff.hi", m->ff.hi, (size_t)M * F * 2}, {"ff.lo", m->ff.lo, (size_t)M * F * 2}, {"xs.hi", m->xs.hi, (size_t)M * 128 * 2},
+                {"qk slack rows", m->qk + (size_t)M * 2 * D, (size_t)256 * 2 * D * 2}};
+            for (auto& b : bufs) {
+                std::vector<unsigned> w(b.bytes / 4);
+                (void)hipMemcpy(w.data(), b.p, b.bytes, hipMemcpyDeviceToHost);
+                unsigned long long acc = 0;
+                for (unsigned x : w) acc = acc * 1000003ull + x;
+                fprintf(stderr, "[dump_qkv] buffer %-14s hash %016llx\n", b.name, acc);
+            }
+        }
         CK(launch_attention(m, st));
         GemmArgs o = gemm_base(m->ao, D, m->wout[l], M);
         o.mul = ml + 2 * D; o.res = m->h; o.ldres = D; o.out_f32 = m->h; o.ldo = D;

@@ -173,10 +173,12 @@ F5_DEVICE void epi_qk_rows_t(const GemmArgs& p, const float* stg, int m_base, in
         const f32x4 v = *reinterpret_cast<const f32x4*>(stg + (q * RPP + r0) * WN + c4) + bv;
         bf16x4 o;
         if (ROT) {
-            o[0] = (__bf16)((v[0] * cs[q].x - v[1] * sn[q].x) * qs);
-            o[1] = (__bf16)((v[1] * cs[q].x + v[0] * sn[q].x) * qs);
-            o[2] = (__bf16)((v[2] * cs[q].y - v[3] * sn[q].y) * qs);
-            o[3] = (__bf16)((v[3] * cs[q].y + v[2] * sn[q].y) * qs);
+            // explicit product + fma: left to the compiler, the contraction of a*c - b*s differs between template instantiations (64- vs
+            // 128-wide wave tiles), a 1-ulp bf16 flip in a few q values that the 22-layer sampler amplifies to 5e-4 (tools/wide_pipeline_check.py)
+            o[0] = (__bf16)(__builtin_fmaf(v[0], cs[q].x, -__fmul_rn(v[1], sn[q].x)) * qs);
+            o[1] = (__bf16)(__builtin_fmaf(v[1], cs[q].x, __fmul_rn(v[0], sn[q].x)) * qs);
+            o[2] = (__bf16)(__builtin_fmaf(v[2], cs[q].y, -__fmul_rn(v[3], sn[q].y)) * qs);
+            o[3] = (__bf16)(__builtin_fmaf(v[3], cs[q].y, __fmul_rn(v[2], sn[q].y)) * qs);
         } else {
 #pragma unroll
             for (int e = 0; e < 4; e++) o[e] = (__bf16)(v[e] * qs);
