@@ -654,6 +654,46 @@ static int forward_unett_layers(f5hip_dit* m, int ti, int n_blocks, hipStream_t 
     return 0;
 }
 
+// Diagnostics (F5HIP_DUMP_QKV = 100 * layer + step): checksums of one QKV projection by column block and a hash of every other workspace
+// buffer, printed to stderr.  This is how the 1-ulp rotary difference between tile widths was found.
+static void debug_dump_qkv(f5hip_dit* m, hipStream_t st) {
+    const int D = m->cfg.dim, F = m->cfg.ff_mult * D, M = m->M;
+   // F5HIP_DUMP_QKV = 100 * layer + step   // diagnostics: checksums of the first QKV projection by column block
+    (void)hipStreamSynchronize(st);
+            std::vector<unsigned short> hq((size_t)M * 2 * D), hv((size_t)D * m->M_pad);
+            (void)hipMemcpy(hq.data(), m->qk, hq.size() * 2, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(hv.data(), m->vt, hv.size() * 2, hipMemcpyDeviceToHost);
+            auto bf = [](unsigned short u) { unsigned v = (unsigned)u << 16; float f; memcpy(&f, &v, 4); return (double)f; };
+            const int edges[6] = {0, 64, 128, 256, 512, D};
+            for (int part = 0; part < 2; part++)
+                for (int e = 0; e < 5; e++) {
+                    double sum = 0, asum = 0;
+                    for (int r = 0; r < M; r++)
+                        for (int c = edges[e]; c < edges[e + 1]; c++) { const double x = bf(hq[(size_t)r * 2 * D + part * D + c]); sum += x; asum += fabs(x); }
+                    fprintf(stderr, "[dump_qkv] %s cols [%d,%d): sum %.6f abs %.6f\n", part ? "K" : "Q", edges[e], edges[e + 1], sum, asum);
+                }
+            for (int e = 0; e < 5; e++) {
+                double sum = 0, asum = 0;
+                for (int c = edges[e]; c < edges[e + 1]; c++)
+                    for (int r = 0; r < M; r++) { const double x = bf(hv[(size_t)c * m->M_pad + r]); sum += x; asum += fabs(x); }
+                fprintf(stderr, "[dump_qkv] V rows [%d,%d): sum %.6f abs %.6f\n", edges[e], edges[e + 1], sum, asum);
+            }
+            // side effects: word checksums of every other workspace buffer (an out-of-bounds store of the projection would show here)
+            struct { const char* name; const void* p; size_t bytes; } bufs[] = {
+                {"h", m->h, (size_t)M * D * 4}, {"h0", m->h0, (size_t)M * D * 4}, {"ce", m->ce, (size_t)M * D * 4}, {"pred", m->pred, (size_t)M * 128 * 4},
+                {"mod", m->mod, (size_t)128 * m->n_adaln * 4}, {"hn.hi", m->hn.hi, (size_t)M * D * 2}, {"hn.lo", m->hn.lo, (size_t)M * D * 2},
+                {"c1.hi", m->c1.hi, (size_t)M * D * 2}, {"ao.hi", m->ao.hi, (size_t)M * D * 2}, {"ao.lo", m->ao.lo, (size_t)M * D * 2},
+                {"ff.hi", m->ff.hi, (size_t)M * F * 2}, {"ff.lo", m->ff.lo, (size_t)M * F * 2}, {"xs.hi", m->xs.hi, (size_t)M * 128 * 2},
+                {"qk slack rows", m->qk + (size_t)M * 2 * D, (size_t)256 * 2 * D * 2}};
+            for (auto& b : bufs) {
+                std::vector<unsigned> w(b.bytes / 4);
+                (void)hipMemcpy(w.data(), b.p, b.bytes, hipMemcpyDeviceToHost);
+                unsigned long long acc = 0;
+                for (unsigned x : w) acc = acc * 1000003ull + x;
+                fprintf(stderr, "[dump_qkv] buffer %-14s hash %016llx\n", b.name, acc);
+            }
+        }
+
 // One DiT evaluation at time index ti for all laid-out sequences.  xs (split bf16 of x) must be current.
 // n_blocks < 0: full network, result in m->pred [M][128];  else stops after n_blocks blocks, result in m->h.
 static int forward_step(f5hip_dit* m, int ti, int n_blocks, hipStream_t st) {
@@ -688,41 +728,7 @@ static int forward_step(f5hip_dit* m, int ti, int n_blocks, hipStream_t st) {
         GemmArgs q = gemm_base(m->hn, D, m->wqkv[l], M);
         q.D = D; q.row_pos = m->d_row_pos; q.rope_cos = m->rope_cos; q.rope_sin = m->rope_sin; q.qk = m->qk; q.vt = m->vt; q.ldvt = m->M_pad;
         CK(run_gemm(m, q, m->wqkv[l], EPI_QKV, false, 128, st));
-        if (getenv("F5HIP_DUMP_QKV") && l == atoi(getenv("F5HIP_DUMP_QKV")) / 100 && ti == atoi(getenv("F5HIP_DUMP_QKV")) % 100) {   // F5HIP_DUMP_QKV = 100 * layer + step   // diagnostics: checksums of the first QKV projection by column block
-            (void)hipStreamSynchronize(st);
-            std::vector<unsigned short> hq((size_t)M * 2 * D), hv((size_t)D * m->M_pad);
-            (void)hipMemcpy(hq.data(), m->qk, hq.size() * 2, hipMemcpyDeviceToHost);
-            (void)hipMemcpy(hv.data(), m->vt, hv.size() * 2, hipMemcpyDeviceToHost);
-            auto bf = [](unsigned short u) { unsigned v = (unsigned)u << 16; float f; memcpy(&f, &v, 4); return (double)f; };
-            const int edges[6] = {0, 64, 128, 256, 512, D};
-            for (int part = 0; part < 2; part++)
-                for (int e = 0; e < 5; e++) {
-                    double sum = 0, asum = 0;
-                    for (int r = 0; r < M; r++)
-                        for (int c = edges[e]; c < edges[e + 1]; c++) { const double x = bf(hq[(size_t)r * 2 * D + part * D + c]); sum += x; asum += fabs(x); }
-                    fprintf(stderr, "[dump_qkv] %s cols [%d,%d): sum %.6f abs %.6f\n", part ? "K" : "Q", edges[e], edges[e + 1], sum, asum);
-                }
-            for (int e = 0; e < 5; e++) {
-                double sum = 0, asum = 0;
-                for (int c = edges[e]; c < edges[e + 1]; c++)
-                    for (int r = 0; r < M; r++) { const double x = bf(hv[(size_t)c * m->M_pad + r]); sum += x; asum += fabs(x); }
-                fprintf(stderr, "[dump_qkv] V rows [%d,%d): sum %.6f abs %.6f\n", edges[e], edges[e + 1], sum, asum);
-            }
-            // side effects: word checksums of every other workspace buffer (an out-of-bounds store of the projection would show here)
-            struct { const char* name; const void* p; size_t bytes; } bufs[] = {
-                {"h", m->h, (size_t)M * D * 4}, {"h0", m->h0, (size_t)M * D * 4}, {"ce", m->ce, (size_t)M * D * 4}, {"pred", m->pred, (size_t)M * 128 * 4},
-                {"mod", m->mod, (size_t)128 * m->n_adaln * 4}, {"hn.hi", m->hn.hi, (size_t)M * D * 2}, {"hn.lo", m->hn.lo, (size_t)M * D * 2},
-                {"c1.hi", m->c1.hi, (size_t)M * D * 2}, {"ao.hi", m->ao.hi, (size_t)M * D * 2}, {"ao.lo", m->ao.lo, (size_t)M * D * 2},
-                {"ff.hi", m->ff.hi, (size_t)M * F * 2}, {"ff.lo", m->ff.lo, (size_t)M * F * 2}, {"xs.hi", m->xs.hi, (size_t)M * 128 * 2},
-                {"qk slack rows", m->qk + (size_t)M * 2 * D, (size_t)256 * 2 * D * 2}};
-            for (auto& b : bufs) {
-                std::vector<unsigned> w(b.bytes / 4);
-                (void)hipMemcpy(w.data(), b.p, b.bytes, hipMemcpyDeviceToHost);
-                unsigned long long acc = 0;
-                for (unsigned x : w) acc = acc * 1000003ull + x;
-                fprintf(stderr, "[dump_qkv] buffer %-14s hash %016llx\n", b.name, acc);
-            }
-        }
+        if (getenv("F5HIP_DUMP_QKV") && l == atoi(getenv("F5HIP_DUMP_QKV")) / 100 && ti == atoi(getenv("F5HIP_DUMP_QKV")) % 100) debug_dump_qkv(m, st);
         CK(launch_attention(m, st));
         GemmArgs o = gemm_base(m->ao, D, m->wout[l], M);
         o.mul = ml + 2 * D; o.res = m->h; o.ldres = D; o.out_f32 = m->h; o.ldo = D;
