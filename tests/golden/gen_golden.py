@@ -221,6 +221,7 @@ def main():
 
     # ---- (4c) UNetT (E2-TTS): parameter order, tiny forward (b=1, both CFG branches), tiny CFM.sample, Small forward ----
     gen_unett_fixtures(cfm_mod, NoMel)
+    gen_e2base_fixtures(cfm_mod, NoMel)
 
     # ---- (5) chunk_text / glue: reference's pure-python functions -----------------------
     gen_glue_fixtures()
@@ -266,6 +267,39 @@ def gen_unett_fixtures(cfm_mod, NoMel):
     with torch.no_grad():
         o1 = net_s(x=xs, cond=cs, text=ts, time=torch.tensor(0.5), drop_audio_cond=False, drop_text=False)
     save("unett_small_forward", x=xs, cond=cs, text=ts, out_cond=o1)
+
+
+def gen_e2base_fixtures(cfm_mod, NoMel, nfe_list=(8, 64)):
+    """BASELINE configs[4] geometry: E2-TTS Base (UNetT 1024/24/16, ff x4), one 20 s chunk behind a 5 s reference = 2340 frames,
+    60 + 240 token ids, CFG 2, sway -1: digests of the reference's own UNetT.forward and CFM.sample (8 and 64 NFE)."""
+    unett_mod = importlib.import_module("f5_tts.model.backbones.unett")
+    arch = dict(dim=1024, depth=24, heads=16, ff_mult=4, text_num_embeds=2545)
+    sd = synth.unett_state_dict(**arch)
+    net = unett_mod.UNetT(**arch, mel_dim=100)
+    net.load_state_dict({k[len("transformer."):]: v for k, v in sd.items()}, strict=True)
+    net = net.eval()
+    n, n_ref = 2340, 469
+    g = torch.Generator().manual_seed(51)
+    xb = synth.noise(n, 0)[None]
+    cb = torch.randn(1, n, 100, generator=g) * (torch.arange(n)[None, :, None] < n_ref)
+    tb = synth.text_ids(60, 240)
+    with torch.no_grad():
+        ob = net(x=xb, cond=cb, text=tb, time=torch.tensor(0.25), drop_audio_cond=False, drop_text=False)
+    idx = torch.randperm(ob.numel(), generator=g)[:4096]
+    save("unett_base_forward_digest", cond=cb.half(), idx=idx, sampled=ob.flatten()[idx], mean=ob.mean(), std=ob.std(),
+         absmax=ob.abs().max())
+    print("e2-base forward done", flush=True)
+    cfm = cfm_mod.CFM(transformer=net, mel_spec_module=NoMel(), num_channels=100, odeint_kwargs=dict(method="euler")).eval()
+    gc = torch.Generator().manual_seed(52)
+    cond = torch.randn(1, n_ref, 100, generator=gc)
+    for steps in nfe_list:
+        out, _ = cfm.sample(cond=cond, text=tb, duration=n, steps=steps, cfg_strength=2.0, sway_sampling_coef=-1.0,
+                            seed=synth.SEED_NOISE)
+        gen = out[0, n_ref:]
+        idx = torch.randperm(gen.numel(), generator=gc)[:16384]
+        save(f"cfm_e2base_sample_digest_s{steps}", idx=idx, sampled=gen.flatten()[idx], mean=gen.mean(), std=gen.std(),
+             absmax=gen.abs().max(), cond_head=out[0, :4])
+        print("e2-base sample", steps, "done", flush=True)
 
 
 def gen_glue_fixtures():
@@ -341,5 +375,14 @@ if __name__ == "__main__":
             n_mel_channels = 100
 
         gen_unett_fixtures(importlib.import_module("f5_tts.model.cfm"), NoMel)
+    elif "--e2base-only" in sys.argv:
+        torch.set_num_threads(8)
+        install_leaf_shims()
+        importlib.import_module("f5_tts.model.modules")
+
+        class NoMel(torch.nn.Identity):
+            n_mel_channels = 100
+
+        gen_e2base_fixtures(importlib.import_module("f5_tts.model.cfm"), NoMel)
     else:
         main()
