@@ -86,6 +86,10 @@ int f5hip_cfm_sample(f5hip_dit* m, int32_t n_utt, const int32_t* dur, const floa
  * ("gemm", "attn", "ln", "other") measured with HIP events on the launch stream, and launch counts. */
 int f5hip_set_profiling(int32_t enabled);
 int f5hip_get_profile(const char* kernel_class, double* total_ms, int64_t* launches);
+/* Launch counters of the GEMM dispatcher since the last reset (test instrumentation: proves which kernel a config exercised):
+ * "gemm5_rb11" / "gemm5_rb8" (exact-fit tile heights 176 / 128), "gemm5_1x4" (128- and 192-column tiles), "gemm3_wide";
+ * name "reset" zeroes all of them (value may be NULL). */
+int f5hip_get_counter(const char* name, int64_t* value);
 
 /* ---------------------------------------------------------------- Vocos vocoder ----------------------- */
 

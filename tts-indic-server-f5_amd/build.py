@@ -1,57 +1,102 @@
 """Builds csrc/libf5hip.so for gfx950 with hipcc (cross-compiles without a GPU).
 
-In-tree on purpose: the .so travels to the GPU box with the repo snapshot."""
+In-tree on purpose: the .so travels to the GPU box with the repo snapshot.  Every kernel family is its own translation
+unit (csrc/tu_*.hip + f5hip.hip), compiled in parallel into csrc/_obj/ and re-compiled only when one of the files it
+includes changed; `--experiments` adds -DF5HIP_EXPERIMENTS (the measured-and-rejected kernels under csrc/experiments/ and
+the f5hip_debug_* entry points the tools/ scripts of round 1 use)."""
 from __future__ import annotations
 
+import concurrent.futures as cf
 import os
+import re
 import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(CSRC, "libf5hip.so")
-SOURCES = ["f5hip.hip"]
-HEADERS = ["common.h", "gemm.h", "gemm2.h", "gemm3.h", "gemm4.h", "gemm_epilogue.h", "attn.h", "attn2.h", "attn3.h", "debug_bench.h", "elementwise.h", "host_util.h", "vocos.h", "bigvgan.h",
-           os.path.join("..", "..", "include", "f5hip.h")]
+UNITS = ["f5hip.hip", "tu_gemm_reg.hip", "tu_gemm3.hip", "tu_gemm5_generic.hip", "tu_gemm5_qkv.hip", "tu_attn.hip"]
+HOT = ("gemm", "attn", "ln_kernel")   # kernels that must not touch scratch memory
+
+_INC = re.compile(r'^\s*#\s*include\s+"([^"]+)"', re.M)
 
 
-def _stale() -> bool:
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+def _deps(path: str, seen: set[str] | None = None) -> set[str]:
+    """The file and everything it includes with "...", recursively (conditional includes count as dependencies too)."""
+    seen = set() if seen is None else seen
+    path = os.path.normpath(path)
+    if path in seen or not os.path.exists(path):
+        return seen
+    seen.add(path)
+    with open(path, encoding="utf-8") as f:
+        for inc in _INC.findall(f.read()):
+            _deps(os.path.join(os.path.dirname(path), inc), seen)
+    return seen
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
-    if not force and not _stale():
-        return LIB
+def _compile(unit: str, flags: list[str], verbose: bool):
+    src, obj = os.path.join(CSRC, unit), os.path.join(OBJ, unit.replace(".hip", ".o"))
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", LIB,
-           os.path.join(CSRC, "f5hip.hip")]
     # -Rpass-analysis=kernel-resource-usage: per-kernel VGPR / scratch report.  A hot kernel that touches scratch pays a
     # scratch set-up per wave plus the spills (a run-time index into the by-value argument struct once cost every GEMM 7 us).
-    cmd.insert(-1, "-Rpass-analysis=kernel-resource-usage")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", "-Rpass-analysis=kernel-resource-usage", *flags, "-o", obj, src]
     if verbose:
         print("[build]", " ".join(cmd), flush=True)
     r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
-    report, name = [], None
+    report, name, vg = [], None, None
     for line in r.stderr.splitlines():
         if "Function Name:" in line:
             name = line.split("Function Name:")[1].split("[-R")[0].strip()
+        elif "VGPRs:" in line and "AGPRs" not in line and name:
+            vg = int(line.split("VGPRs:")[1].split()[0])
         elif "ScratchSize [bytes/lane]:" in line and name:
-            report.append((name, int(line.split("ScratchSize [bytes/lane]:")[1].split()[0])))
+            report.append((name, int(line.split("ScratchSize [bytes/lane]:")[1].split()[0]), vg))
             name = None
     if r.returncode != 0:
         sys.stderr.write("\n".join(l for l in r.stderr.splitlines() if "remark:" not in l) + "\n")
         raise subprocess.CalledProcessError(r.returncode, cmd)
+    with open(obj + ".resources", "w") as f:
+        for n, sc, v in report:
+            f.write(f"{sc:6d} B scratch  {v if v is not None else -1:4d} VGPR  {n}\n")
+    return unit
+
+
+def build(force: bool = False, verbose: bool = True, experiments: bool = False) -> str:
+    os.makedirs(OBJ, exist_ok=True)
+    flags = ["-DF5HIP_EXPERIMENTS"] if experiments else []
+    stamp = os.path.join(OBJ, "flags.txt")
+    if not os.path.exists(stamp) or open(stamp).read() != " ".join(flags):
+        force = True
+    stale = []
+    for u in UNITS:
+        obj = os.path.join(OBJ, u.replace(".hip", ".o"))
+        if force or not os.path.exists(obj) or any(os.path.getmtime(d) > os.path.getmtime(obj) for d in _deps(os.path.join(CSRC, u))):
+            stale.append(u)
+    if stale:
+        with cf.ThreadPoolExecutor(max_workers=min(len(stale), max(1, (os.cpu_count() or 2) - 1))) as ex:
+            for u in ex.map(lambda u: _compile(u, flags, verbose), stale):
+                pass
+        with open(stamp, "w") as f:
+            f.write(" ".join(flags))
+    objs = [os.path.join(OBJ, u.replace(".hip", ".o")) for u in UNITS]
+    if stale or not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
+        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+        if verbose:
+            print("[build]", " ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    lines = []
+    for o in objs:
+        if os.path.exists(o + ".resources"):
+            lines += open(o + ".resources").read().splitlines()
     with open(os.path.join(CSRC, "kernel_resources.txt"), "w") as f:
-        for n, sc in report:
-            f.write(f"{sc:6d} B scratch  {n}\n")
-    hot = [n for n, sc in report if sc and any(k in n for k in ("gemm", "attn", "ln_kernel"))]
+        f.write("\n".join(lines) + "\n")
+    hot = [l.split("VGPR", 1)[1].strip() for l in lines if not l.lstrip().startswith("0 B") and any(k in l for k in HOT)]
     if hot:
         raise RuntimeError("hot kernels use scratch memory: " + ", ".join(hot))
     return LIB
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    build(force="--force" in sys.argv, experiments="--experiments" in sys.argv)

@@ -7,9 +7,9 @@
 // softmax of S_cur runs on the VALU while those MFMAs execute, then O += V_j P.  The LDS ring is 5 deep so the K tile
 // one step ahead is resident while 3 more tiles stay in flight.
 #pragma once
-#include "attn2.h"
+#include "attn_common.h"
 
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn3_fwd_kernel(const AttnArgs p) {
+static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn3_fwd_kernel(const AttnArgs p) {
     constexpr int NST = 5, STAGE = 16384;
     __shared__ __attribute__((aligned(16))) char smem[NST * STAGE];
     const int seq = blockIdx.z, head = blockIdx.y;

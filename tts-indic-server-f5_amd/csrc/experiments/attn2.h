@@ -1,66 +1,52 @@
-// Flash-style non-causal self-attention forward for gfx950, head dim 64, bf16 MFMA, fp32 online softmax.
+// attn2: 8-wave, LDS-DMA-fed version of the flash attention forward (same math and fragment scheme as attn.h).
 //
-//  one workgroup = 128 queries of one (sequence, head); 4 waves x 32 queries; KV tiles of 64 keys.
-//  Per KV tile each wave computes S^T = K Q^T (keys on accumulator rows, queries on lanes), so the row max /
-//  row sum of a query are in-register reductions plus one lane^32 exchange, and the exponentiated tile is
-//  already the B operand of O^T += V^T P^T (guide: "an accumulator tile as the next MFMA's operand") -- no
-//  LDS round trip for P.  V arrives transposed ([d][token], written by the QKV GEMM epilogue) so the permuted
-//  k order of that operand is two 8-byte LDS reads.  Q is pre-scaled by 1/8 in the QKV epilogue.
-//  Keys >= kv_len are masked to -1e30 before the max (key-padding mask, F/model/modules.py:429-434).
+// rocprof on attn.h (4 waves, 128 queries, register-staged K/V with one tile in flight) showed ~2500 cycles per KV
+// tile against 512 MFMA cycles per wave: the loop waits on the ~1 us global->LDS latency every tile, and at one
+// utterance per GPU its 352 workgroups need two rounds on 256 CUs.  Here one 512-thread workgroup owns 256 queries
+// (192 workgroups at N = 1404: one round), the K and V^T tiles of 64 keys arrive by LDS-DMA (global_load_lds_dwordx4,
+// 2 pieces per wave per tile) into a 4-deep ring (3 tiles = 48 KiB in flight), with a counted s_waitcnt vmcnt and one
+// raw s_barrier per tile; the O rescale is skipped whenever no running maximum of the wave moved (exact: alpha == 1).
 #pragma once
-#include "common.h"
+#include "attn.h"
 
-struct AttnArgs {
-    const __bf16* qk;   // [M_pad][2 D]   q | k
-    const __bf16* vt;   // [D][ldvt]
-    int D, ldvt;
-    const int* seq_row0;
-    const int* seq_len;
-    const int* seq_kvlen;
-    __bf16* out_hi;     // [M_pad][D]
-    __bf16* out_lo;     // may be null
-    int f16_out;        // 1: out_hi receives one fp16 plane (A operand of the fp16 out-projection GEMM)
-    unsigned long long* dbg;   // diagnostics (attn3): per-phase s_memtime totals of wave 0 of workgroup (0,0,0), or null
-};
-
-F5_DEVICE int lds_off128(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
-
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_fwd_kernel(const AttnArgs p) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * 16384];
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn2_fwd_kernel(const AttnArgs p) {
+    constexpr int NST = 4, STAGE = 16384;
+    __shared__ __attribute__((aligned(16))) char smem[NST * STAGE];
     const int seq = blockIdx.z, head = blockIdx.y;
     const int len = p.seq_len[seq], kvlen = p.seq_kvlen[seq], row0 = p.seq_row0[seq];
-    const int q0 = blockIdx.x * 128;
+    const int q0 = blockIdx.x * 256;
     if (q0 >= len) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 31, fh = lane >> 5;
     const int D = p.D;
     const float LOG2E = 1.4426950408889634f;
 
+    // queries of this wave (rows beyond the sequence stay inside its 128-row padding or the next sequence: finite data,
+    // never stored).  q0 + 255 can exceed the padded rows of the LAST sequence only by < 256 rows: workspace has slack.
     bf16x8 qf[4];
     {
         const __bf16* qrow = p.qk + (size_t)(row0 + q0 + wave * 32 + fr) * (2 * D) + head * 64 + fh * 8;
 #pragma unroll
         for (int s = 0; s < 4; s++) qf[s] = *reinterpret_cast<const bf16x8*>(qrow + s * 16);
     }
+    // Retire the Q loads BEFORE the first LDS-DMA is issued: with a DMA in flight hipcc can only wait vmcnt(0) for an
+    // ordinary VGPR load, and it would put that wait inside the KV loop, draining the ring every tile.
+    asm volatile("" ::"v"(qf[0]), "v"(qf[1]), "v"(qf[2]), "v"(qf[3]) : "memory");
 
-    const int nkt = (kvlen + 63) >> 6;
-    u32x4 rk[2], rv[2];
-    auto load_kv = [&](int kt) {
-#pragma unroll
-        for (int i = 0; i < 2; i++) {
-            const int idx = tid + 256 * i, r = idx >> 3, c = idx & 7;
-            rk[i] = *reinterpret_cast<const u32x4*>(p.qk + (size_t)(row0 + kt * 64 + r) * (2 * D) + D + head * 64 + c * 8);
-            rv[i] = *reinterpret_cast<const u32x4*>(p.vt + (size_t)(head * 64 + r) * p.ldvt + row0 + kt * 64 + c * 8);
-        }
-    };
-    auto store_kv = [&](int stage) {
-        char* base = smem + stage * 16384;
-#pragma unroll
-        for (int i = 0; i < 2; i++) {
-            const int idx = tid + 256 * i, r = idx >> 3, c = idx & 7;
-            *reinterpret_cast<u32x4*>(base + lds_off128(r, c)) = rk[i];
-            *reinterpret_cast<u32x4*>(base + 8192 + lds_off128(r, c)) = rv[i];
-        }
+    // LDS-DMA: a KV tile is 8 K pieces + 8 V^T pieces of 1 KiB (8 rows x 128 B); wave w moves K piece w and V piece w.
+    // Physical 16-B slot (lane & 7) of row r holds logical chunk (lane & 7) ^ ((r >> 1) & 7)  (same swizzle as attn.h).
+    const int prow = wave * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((prow >> 1) & 7);
+    const char* ksrc = reinterpret_cast<const char*>(p.qk + (size_t)(row0 + prow) * (2 * D) + D + head * 64 + chunk * 8);
+    const char* vsrc = reinterpret_cast<const char*>(p.vt + (size_t)(head * 64 + prow) * p.ldvt + row0 + chunk * 8);
+    const size_t kstep = (size_t)64 * (2 * D) * 2, vstep = 64 * 2;   // bytes per KV tile
+    auto issue_tile = [&](int kt) {
+        char* dst = smem + (kt % NST) * STAGE + wave * 1024;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ksrc + kt * kstep),
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vsrc + kt * vstep),
+                                         (__attribute__((address_space(3))) void*)(dst + 8192), 16, 0, 0);
     };
 
     f32x16 oacc[2];
@@ -70,14 +56,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int g = 0; g < 16; g++) oacc[dt][g] = 0.0f;
     float mrun = -1e30f, lrun = 0.0f;
 
-    load_kv(0);
-    store_kv(0);
-    __syncthreads();
+    const int nkt = (kvlen + 63) >> 6;
+#pragma unroll
+    for (int t = 0; t < NST - 1; t++)
+        if (t < nkt) issue_tile(t);
 
     for (int kt = 0; kt < nkt; kt++) {
-        const bool more = kt + 1 < nkt;
-        if (more) load_kv(kt + 1);
-        const char* kst = smem + (kt & 1) * 16384;
+        const int newer = min(NST - 2, nkt - 1 - kt);
+        if (newer >= 2) attn_wait_vmcnt<4>();
+        else if (newer == 1) attn_wait_vmcnt<2>();
+        else attn_wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (kt + NST - 1 < nkt) issue_tile(kt + NST - 1);
+        const char* kst = smem + (kt % NST) * STAGE;
         const char* vst = kst + 8192;
 
         f32x16 sacc[2];
@@ -107,6 +98,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int g = 0; g < 16; g++) mloc = fmaxf(mloc, sacc[kh][g]);
         mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
         const float mnew = fmaxf(mrun, mloc);
+        const bool moved = mnew != mrun;
         const float alpha = __builtin_amdgcn_exp2f((mrun - mnew) * LOG2E);
         mrun = mnew;
         const float msc = mnew * LOG2E;
@@ -120,11 +112,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 rowsum += pv;
             }
         lrun = lrun * alpha + rowsum;
+        if (__any(moved)) {   // wave-uniform; alpha == 1 exactly for every query whose maximum did not move
 #pragma unroll
-        for (int dt = 0; dt < 2; dt++)
+            for (int dt = 0; dt < 2; dt++)
 #pragma unroll
-            for (int g = 0; g < 16; g++) oacc[dt][g] *= alpha;
-
+                for (int g = 0; g < 16; g++) oacc[dt][g] *= alpha;
+        }
 #pragma unroll
         for (int kh = 0; kh < 2; kh++) {
 #pragma unroll
@@ -144,8 +137,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 }
             }
         }
-        if (more) store_kv((kt + 1) & 1);
-        __syncthreads();
     }
 
     const float ltot = lrun + __shfl_xor(lrun, 32, 64);

@@ -12,9 +12,7 @@
 //   * 8 waves split the tile 2 x 4 (64 x 32 per wave) or 4 x 2 (64 x 64 per wave); epilogue shared with gemm.h.
 // Restrictions: no implicit-conv operand (those GEMMs stay on gemm.h), K % 32 == 0, M_pad % BM == 0, N_pad % BN == 0.
 #pragma once
-#include "gemm_epilogue.h"
-
-F5_DEVICE int lds_off2(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
+#include "../gemm_epilogue.h"
 
 template <int NSPLIT, int BM, int BN>
 struct Gemm2Cfg {
@@ -30,9 +28,6 @@ struct Gemm2Cfg {
     static_assert(PIECES % 8 == 0, "pieces must divide over 8 waves");
     static_assert(LDS >= 8 * TM * TN * 4096, "ring must hold the epilogue slabs");
 };
-
-template <int N>
-F5_DEVICE void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 template <int NSPLIT, int BM, int BN, int EPI>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm2_kernel(const GemmArgs p) {

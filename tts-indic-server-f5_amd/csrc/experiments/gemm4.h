@@ -21,7 +21,7 @@
 // s_barrier per k-step.  The ring runs straight across segment boundaries.  The epilogue slabs have their own 64 KiB of
 // LDS (not aliased with the ring), so the producers keep prefetching the next segment while the consumers finish a tile.
 #pragma once
-#include "gemm3.h"
+#include "../gemm3.h"
 
 struct StreamKWs {
     float* slots = nullptr;        // [grid][4 waves][64 regs][64 lanes] fp32

@@ -11,16 +11,17 @@
 #include <string>
 #include <vector>
 
-#include "attn.h"
-#include "attn2.h"
-#include "attn3.h"
 #include "common.h"
 #include "elementwise.h"
-#include "gemm.h"
-#include "gemm2.h"
-#include "gemm3.h"
-#include "gemm4.h"
+#include "gemm_launch.h"
 #include "host_util.h"
+#ifdef F5HIP_EXPERIMENTS   // measured-and-rejected kernels kept for A/B (stream-K GEMM, 8-wave all-consume GEMM, earlier attention kernels)
+#include "experiments/attn2.h"
+#include "experiments/gemm2.h"
+#include "experiments/gemm4.h"
+#include "gemm.h"
+#include "attn3.h"
+#endif
 
 // =================================================================================================
 // DiT model
@@ -34,7 +35,9 @@ struct TextBlock {
 struct f5hip_dit {
     f5hip_dit_config cfg;
     int nsplit = 2;       // operand planes of the state-touching GEMMs (1 bf16, 2 split bf16)
-    StreamKWs sk;         // stream-K partial-tile slots + flags (gemm4.h), owned by the handle: launches of one handle are stream-ordered
+#ifdef F5HIP_EXPERIMENTS
+    StreamKWs sk;         // stream-K partial-tile slots + flags (experiments/gemm4.h), owned by the handle: launches of one handle are stream-ordered
+#endif
     bool blk_f16 = false; // gemm_planes == 3: transformer-block GEMMs (QKV, out, FF1, FF2) take one fp16 plane per operand (DiT)
     std::map<std::string, std::vector<float>> host;
     bool finalized = false;
@@ -107,7 +110,9 @@ void f5hip_dit_destroy(f5hip_dit* m) {
     }
     for (float* p : {m->text_emb, m->text_pos, m->rope_cos, m->rope_sin}) dev_free(p);
     dev_free(m->ws.ptr);
+#ifdef F5HIP_EXPERIMENTS
     streamk_ws_free(m->sk);
+#endif
     dev_free(m->meta);
     delete m;
 }
@@ -394,79 +399,68 @@ static GemmArgs gemm_base(const Plane2& A, int lda, const PackedW& W, int M) {
     return a;
 }
 
-static int g_gemm_impl = -1;   // 0 = automatic, 1 = register-staged 4-wave kernel only (gemm.h), 2 = LDS-DMA ring kernel wherever applicable (gemm2.h)
+static int g_gemm_impl = -1;   // F5HIP_GEMM_IMPL: 0 = automatic; 1 = register-staged kernel only (gemm.h); 3 = gemm3 instead of gemm5 (A/B); 2 / 4 = experiments build only
+static long long g_counters[4] = {0, 0, 0, 0};   // f5hip_get_counter: gemm5 launches with RB 11 / RB 8 / 1 x 4 consumer layout / gemm3 wide-tile launches
 
-static int run_gemm_n(int nsplit, int mp, GemmArgs& a, const PackedW& W, int epi, bool conv, int bn, hipStream_t st, StreamKWs* sk = nullptr) {
+// Kernel choice per GEMM (measured: profiles/r02_fillrate_microbench.txt, profiles/r01_gemm_microbench.txt, tools/gemm_microbench.py):
+//   fp16 one-plane operands with K % 64 == 0 (the four transformer-block GEMMs of the DiT in mixed mode): gemm5, exact-fit tiles;
+//   one 128 x 128 tile per CU or fewer, generic epilogue, bf16 / split-bf16 operands: gemm3 (warp-specialised LDS-DMA ring);
+//   everything else (implicit-GEMM convolutions, QKV in split-bf16, many-tile shapes): gemm.h, two 4-wave workgroups per CU.
+static int run_gemm_n(int nsplit, int mp, GemmArgs& a, const PackedW& W, int epi, bool conv, int bn, hipStream_t st, void* sk = nullptr) {
     hipError_t e;
     const int np = W.n_pad;
     if (mp % 128 || np % bn || a.K % 32) return fail(-7, "gemm: bad padded shape %d x %d x %d", mp, np, a.K);
     if (g_gemm_impl < 0) {
         const char* env = getenv("F5HIP_GEMM_IMPL");
-        g_gemm_impl = env ? atoi(env) : 0;   // 0 = automatic
+        g_gemm_impl = env ? atoi(env) : 0;
     }
+    (void)sk;
     prof_begin(PROF_GEMM, st);
-    // Kernel choice (tools/gemm_microbench.py + rocprof, MI355X): with at most one 128 x 128 tile per CU the 8-wave LDS-DMA
-    // kernel finishes a tile ~1.3x sooner than the 4-wave register-staged one; with more tiles than CUs two co-resident
-    // 4-wave workgroups hide each other's prologue / epilogue and win.  F5HIP_GEMM_IMPL=1 / 2 forces one kernel.
     const long long tiles128 = (long long)(mp / 128) * (np / 128);
-    const bool use2 = !conv && (g_gemm_impl == 2 || (g_gemm_impl == 0 && tiles128 <= 256 && epi != EPI_QKV));
     const bool use3 = !conv && (g_gemm_impl == 3 || (g_gemm_impl == 0 && tiles128 <= 256 && epi != EPI_QKV));
-    // stream-K (gemm4.h): every CU gets the same number of k-steps.  Opt-in only (F5HIP_GEMM_IMPL=4): parity-green, but measured
-    // 5-25 % SLOWER than the data-parallel kernels at every C2 shape (rocprof: QKV 43.5 vs 39.9 us, out 21.3 vs 17, FF1 32.6 vs 29.2):
-    // the partial-tile exchange costs more than the balance wins while the k-loop is bound by operand traffic, not by the MFMAs.
+#ifdef F5HIP_EXPERIMENTS
     const int nk32 = a.K >> 5;
-    const bool can4 = sk && !conv && nsplit != 2 && np % 128 == 0 && nk32 >= 16 && tiles128 >= 64;   // (the split-bf16 instantiation spills: not built)
-    if (can4 && g_gemm_impl == 4) {
-        if (streamk_ws_init(*sk)) { prof_end(PROF_GEMM, st); return fail(-5, "stream-K workspace"); }
-        if (nsplit == 3) e = epi == EPI_QKV ? launch_gemm4_t<3, EPI_QKV>(a, mp, np, *sk, st) : launch_gemm4_t<3, EPI_GENERIC>(a, mp, np, *sk, st);
-        else e = epi == EPI_QKV ? launch_gemm4_t<1, EPI_QKV>(a, mp, np, *sk, st) : launch_gemm4_t<1, EPI_GENERIC>(a, mp, np, *sk, st);
-    } else if (nsplit == 3) {   // fp16 operands (one plane each): the warp-specialised kernel wins at every batch-1 shape (tools/gemm_microbench.py)
+    StreamKWs* skw = (StreamKWs*)sk;
+    if (g_gemm_impl == 4 && skw && !conv && nsplit != 2 && np % 128 == 0 && nk32 >= 16 && tiles128 >= 64) {   // stream-K: 5-25 % slower at every C2 shape
+        if (streamk_ws_init(*skw)) { prof_end(PROF_GEMM, st); return fail(-5, "stream-K workspace"); }
+        if (nsplit == 3) e = epi == EPI_QKV ? launch_gemm4_t<3, EPI_QKV>(a, mp, np, *skw, st) : launch_gemm4_t<3, EPI_GENERIC>(a, mp, np, *skw, st);
+        else e = epi == EPI_QKV ? launch_gemm4_t<1, EPI_QKV>(a, mp, np, *skw, st) : launch_gemm4_t<1, EPI_GENERIC>(a, mp, np, *skw, st);
+    } else if (g_gemm_impl == 2 && !conv && nsplit != 3) {
+        if (nsplit == 2) e = epi == EPI_QKV ? launch_gemm2_t<2, 128, 128, EPI_QKV>(a, mp, np, st) : launch_gemm2_t<2, 128, 128, EPI_GENERIC>(a, mp, np, st);
+        else e = epi == EPI_QKV ? launch_gemm2_t<1, 128, 128, EPI_QKV>(a, mp, np, st) : launch_gemm2_t<1, 128, 128, EPI_GENERIC>(a, mp, np, st);
+    } else
+#endif
+    if (nsplit == 3) {   // fp16 operands, one plane each
         if (conv) { prof_end(PROF_GEMM, st); return fail(-7, "gemm: fp16 operands are not built for the implicit-GEMM convolution"); }
-        // 128 x 256 tile (gemm3 BN = 256): 25 % fewer operand bytes per FLOP; FF2 -15 %, QKV -8 %, FF1 -3 % at 8 utterances (tools/gemm_wide_ab.py),
-        // nothing at one.  Default: batch mode (>= 1024 tiles of 128 x 128).  Bit-identical to the 128 x 128 tile in isolation
-        // (tools/gemm_wide_check.py) and inside the sampler (tests/test_gpu_dit.py::test_batch_of_copies_equals_single).
-        // F5HIP_WIDE=<min tiles> (+ F5HIP_WIDE_QKV_ONLY / F5HIP_WIDE_GENERIC_ONLY) overrides for diagnostics.
-        static const bool want_wide = getenv("F5HIP_WIDE") != nullptr;
-        static const bool wide_qkv_only = getenv("F5HIP_WIDE_QKV_ONLY") != nullptr, wide_gen_only = getenv("F5HIP_WIDE_GENERIC_ONLY") != nullptr;
-        static const int wide_min_tiles = want_wide ? atoi(getenv("F5HIP_WIDE")) : 1024;
-        const bool wide_ok = (wide_qkv_only ? epi == EPI_QKV : true) && (wide_gen_only ? epi != EPI_QKV : true);
-        const bool wide = g_gemm_impl == 0 && wide_ok && tiles128 >= wide_min_tiles && np % 256 == 0;
-        if (wide) e = epi == EPI_QKV ? launch_gemm3_t<3, EPI_QKV, 0, 256>(a, mp, np, st) : launch_gemm3_t<3, EPI_GENERIC, 0, 256>(a, mp, np, st);
-        else if (g_gemm_impl == 1) e = epi == EPI_QKV ? launch_gemm_t<3, 128, false, EPI_QKV>(a, mp, np, st) : launch_gemm_t<3, 128, false, EPI_GENERIC>(a, mp, np, st);
-        else e = epi == EPI_QKV ? launch_gemm3_t<3, EPI_QKV>(a, mp, np, st) : launch_gemm3_t<3, EPI_GENERIC>(a, mp, np, st);
-    } else if (use3) {   // warp-specialised producer / consumer kernel: one tile per CU finishes soonest on it (microbench: 30.5 vs 31.0 vs 41 us)
-        if (nsplit == 2) e = epi == EPI_QKV ? launch_gemm3_t<2, EPI_QKV>(a, mp, np, st) : launch_gemm3_t<2, EPI_GENERIC>(a, mp, np, st);
-        else e = epi == EPI_QKV ? launch_gemm3_t<1, EPI_QKV>(a, mp, np, st) : launch_gemm3_t<1, EPI_GENERIC>(a, mp, np, st);
-    } else if (use2) {
-        const bool big = mp % 256 == 0 && tiles128 >= 4 * 256 && epi != EPI_QKV;
-        if (nsplit == 2) {
-            if (epi == EPI_QKV) e = launch_gemm2_t<2, 128, 128, EPI_QKV>(a, mp, np, st);
-            else if (big) e = launch_gemm2_t<2, 256, 128, EPI_GENERIC>(a, mp, np, st);
-            else e = launch_gemm2_t<2, 128, 128, EPI_GENERIC>(a, mp, np, st);
+        const Gemm5Choice c5 = gemm5_choose(a.M, np);
+        if ((g_gemm_impl == 0 || g_gemm_impl == 5) && a.K % 64 == 0 && c5.rb) {
+            e = epi == EPI_QKV ? f5_launch_gemm5_qkv(a, c5.rb, c5.cb, np, st) : f5_launch_gemm5_generic(a, c5.rb, c5.cb, np, st);
+            g_counters[c5.rb == 11 ? 0 : 1]++;
+            if (c5.cb >= 8) g_counters[2]++;
+        } else if (g_gemm_impl == 1) {
+            e = f5_launch_gemm_reg(3, 128, false, epi, a, mp, np, st);
         } else {
-            if (epi == EPI_QKV) e = launch_gemm2_t<1, 128, 128, EPI_QKV>(a, mp, np, st);
-            else if (big) e = launch_gemm2_t<1, 256, 128, EPI_GENERIC>(a, mp, np, st);
-            else e = launch_gemm2_t<1, 128, 128, EPI_GENERIC>(a, mp, np, st);
+            // gemm3 (round 1): 128 x 256 tile in batch mode (>= 1024 tiles of 128 x 128), 128 x 128 otherwise
+            const bool wide = tiles128 >= 1024 && np % 256 == 0;
+            if (wide) g_counters[3]++;
+            e = f5_launch_gemm3(3, epi, wide ? 256 : 128, a, mp, np, st);
         }
-    } else if (nsplit == 2) {
-        if (epi == EPI_QKV) e = launch_gemm_t<2, 128, false, EPI_QKV>(a, mp, np, st);
-        else if (conv && bn == 64) e = launch_gemm_t<2, 64, true, EPI_GENERIC>(a, mp, np, st);
-        else if (conv) e = launch_gemm_t<2, 128, true, EPI_GENERIC>(a, mp, np, st);
-        else if (bn == 64) e = launch_gemm_t<2, 64, false, EPI_GENERIC>(a, mp, np, st);
-        else e = launch_gemm_t<2, 128, false, EPI_GENERIC>(a, mp, np, st);
+    } else if (use3) {
+        e = f5_launch_gemm3(nsplit, epi, 128, a, mp, np, st);
     } else {
-        if (epi == EPI_QKV) e = launch_gemm_t<1, 128, false, EPI_QKV>(a, mp, np, st);
-        else if (conv && bn == 64) e = launch_gemm_t<1, 64, true, EPI_GENERIC>(a, mp, np, st);
-        else if (conv) e = launch_gemm_t<1, 128, true, EPI_GENERIC>(a, mp, np, st);
-        else if (bn == 64) e = launch_gemm_t<1, 64, false, EPI_GENERIC>(a, mp, np, st);
-        else e = launch_gemm_t<1, 128, false, EPI_GENERIC>(a, mp, np, st);
+        e = f5_launch_gemm_reg(nsplit, bn, conv, epi, a, mp, np, st);
     }
     prof_end(PROF_GEMM, st);
     if (e != hipSuccess) return fail(-7, "gemm launch: %s", hipGetErrorString(e));
     return 0;
 }
 static int run_gemm(f5hip_dit* m, GemmArgs& a, const PackedW& W, int epi, bool conv, int bn, hipStream_t st, int m_pad = -1) {
-    return run_gemm_n(W.f16 ? 3 : m->nsplit, m_pad > 0 ? m_pad : m->M_pad, a, W, epi, conv, bn, st, &m->sk);
+#ifdef F5HIP_EXPERIMENTS
+    void* sk = &m->sk;
+#else
+    void* sk = nullptr;
+#endif
+    return run_gemm_n(W.f16 ? 3 : m->nsplit, m_pad > 0 ? m_pad : m->M_pad, a, W, epi, conv, bn, st, sk);
 }
 
 static int run_ln(const LnArgs& a, hipStream_t st) {
@@ -485,6 +479,16 @@ static int run_ln(const LnArgs& a, hipStream_t st) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(-7, "ln launch: %s", hipGetErrorString(e));
     return 0;
+}
+
+// Diagnostics for tests: which GEMM path the launches since the last reset took ("gemm5_rb11", "gemm5_rb8", "gemm5_1x4", "gemm3_wide"); name "reset" zeroes them.
+extern "C" int f5hip_get_counter(const char* name, int64_t* value) {
+    static const char* names[4] = {"gemm5_rb11", "gemm5_rb8", "gemm5_1x4", "gemm3_wide"};
+    if (!name) return fail(-1, "get_counter: null name");
+    if (!strcmp(name, "reset")) { for (auto& c : g_counters) c = 0; return 0; }
+    for (int i = 0; i < 4; i++)
+        if (!strcmp(name, names[i])) { if (value) *value = g_counters[i]; return 0; }
+    return fail(-1, "unknown counter %s", name);
 }
 
 #define CK(x) do { int _r = (x); if (_r) return _r; } while (0)
@@ -583,12 +587,15 @@ static int launch_attention(f5hip_dit* m, hipStream_t st) {
     AttnArgs at; memset(&at, 0, sizeof(at));
     at.qk = m->qk; at.vt = m->vt; at.D = c.dim; at.ldvt = m->M_pad; at.seq_row0 = m->d_seq_row0; at.seq_len = m->d_seq_len;
     at.seq_kvlen = m->d_seq_kvlen; at.out_hi = m->ao.hi; at.out_lo = m->nsplit == 2 ? m->ao.lo : nullptr; at.f16_out = m->blk_f16 ? 1 : 0;
+    prof_begin(PROF_ATTN, st);
+#ifdef F5HIP_EXPERIMENTS
     static int attn_impl = -1;
     if (attn_impl < 0) { const char* env = getenv("F5HIP_ATTN_IMPL"); attn_impl = env ? atoi(env) : 3; }
-    prof_begin(PROF_ATTN, st);
     if (attn_impl == 1) hipLaunchKernelGGL(attn_fwd_kernel, dim3((m->max_len + 127) / 128, c.heads, m->n_seq), dim3(256), 0, st, at);
     else if (attn_impl == 2) hipLaunchKernelGGL(attn2_fwd_kernel, dim3((m->max_len + 255) / 256, c.heads, m->n_seq), dim3(512), 0, st, at);
-    else hipLaunchKernelGGL(attn3_fwd_kernel, dim3((m->max_len + 255) / 256, c.heads, m->n_seq), dim3(512), 0, st, at);
+    else
+#endif
+    if (hipError_t e = f5_launch_attn3(at, m->max_len, c.heads, m->n_seq, st); e != hipSuccess) { prof_end(PROF_ATTN, st); return fail(-7, "attention launch: %s", hipGetErrorString(e)); }
     prof_end(PROF_ATTN, st);
     CKL("attention");
     return 0;
@@ -728,7 +735,8 @@ static int forward_step(f5hip_dit* m, int ti, int n_blocks, hipStream_t st) {
         GemmArgs q = gemm_base(m->hn, D, m->wqkv[l], M);
         q.D = D; q.row_pos = m->d_row_pos; q.rope_cos = m->rope_cos; q.rope_sin = m->rope_sin; q.qk = m->qk; q.vt = m->vt; q.ldvt = m->M_pad;
         CK(run_gemm(m, q, m->wqkv[l], EPI_QKV, false, 128, st));
-        if (getenv("F5HIP_DUMP_QKV") && l == atoi(getenv("F5HIP_DUMP_QKV")) / 100 && ti == atoi(getenv("F5HIP_DUMP_QKV")) % 100) debug_dump_qkv(m, st);
+        static const int dump_qkv = getenv("F5HIP_DUMP_QKV") ? atoi(getenv("F5HIP_DUMP_QKV")) : -1;   // diagnostics, read once
+        if (dump_qkv >= 0 && l == dump_qkv / 100 && ti == dump_qkv % 100) debug_dump_qkv(m, st);
         CK(launch_attention(m, st));
         GemmArgs o = gemm_base(m->ao, D, m->wout[l], M);
         o.mul = ml + 2 * D; o.res = m->h; o.ldres = D; o.out_f32 = m->h; o.ldo = D;
@@ -851,4 +859,6 @@ int f5hip_cfm_sample(f5hip_dit* m, int32_t n_utt, const int32_t* dur, const floa
 
 #include "vocos.h"
 #include "bigvgan.h"
-#include "debug_bench.h"
+#ifdef F5HIP_EXPERIMENTS
+#include "experiments/debug_bench.h"
+#endif

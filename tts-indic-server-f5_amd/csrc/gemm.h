@@ -192,13 +192,8 @@ static hipError_t launch_gemm_t(const GemmArgs& a, int m_pad, int n_pad, hipStre
     constexpr int EPI_LDS = (128 / (4 / (BN / 64)) / 32) * 2 * 4096 * 4;   // 4 waves x (TM x TN) x 4 KiB epilogue slabs
     constexpr int NPL = NSPLIT == 2 ? 2 : 1;
     constexpr int LDS = 2 * NPL * (128 + BN) * 64 < EPI_LDS ? EPI_LDS : 2 * NPL * (128 + BN) * 64;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<NSPLIT, BN, CONV, EPI, ABL>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static unsigned attr_mask = 0;
+    if (hipError_t e = f5_set_lds_attr(reinterpret_cast<const void*>(&gemm_kernel<NSPLIT, BN, CONV, EPI, ABL>), LDS, attr_mask); e != hipSuccess) return e;
     dim3 grid(n_pad / BN, m_pad / 128);
     hipLaunchKernelGGL((gemm_kernel<NSPLIT, BN, CONV, EPI, ABL>), grid, dim3(256), LDS, st, a);
     return hipGetLastError();

@@ -14,7 +14,7 @@
 // One raw s_barrier per k-tile joins both groups: "tile kt has landed" for the consumers, "tile kt-1 is consumed" for
 // the producers, which then refill that stage.  Same LDS image / swizzle / epilogue as gemm2.h.
 #pragma once
-#include "gemm2.h"
+#include "gemm_epilogue.h"
 
 // ABL (diagnostics only): 0 = normal, 1 = producers issue no DMA (consumers read whatever is in LDS), 2 = consumers skip the MFMAs,
 // 4 = consumers skip the MFMAs AND the producers re-fetch k-tile 0 every step (cache-hot addresses: the DMA issue rate alone)
@@ -165,12 +165,8 @@ static hipError_t launch_gemm3_t(const GemmArgs& a, int m_pad, int n_pad, hipStr
     constexpr int RING = 4 * NPL * (128 + BN) * 64, SLABS = 4 * 64 * (BN / 2) * 4;   // k-loop ring; four 64 x BN/2 fp32 epilogue slabs
     constexpr int LDS = RING > SLABS ? RING : SLABS;
     static_assert(LDS <= 160 * 1024, "tile does not fit the LDS");
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm3_kernel<NSPLIT, EPI, ABL, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static unsigned attr_mask = 0;
+    if (hipError_t e = f5_set_lds_attr(reinterpret_cast<const void*>(&gemm3_kernel<NSPLIT, EPI, ABL, BN>), LDS, attr_mask); e != hipSuccess) return e;
     dim3 grid(n_pad / BN, m_pad / 128);
     hipLaunchKernelGGL((gemm3_kernel<NSPLIT, EPI, ABL, BN>), grid, dim3(512), LDS, st, a);
     return hipGetLastError();

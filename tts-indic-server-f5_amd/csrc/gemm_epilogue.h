@@ -10,6 +10,24 @@
 
 enum { EPI_GENERIC = 0, EPI_QKV = 1 };
 
+// 64-byte LDS rows (32-deep k-steps of gemm.h / gemm3.h): 16-byte chunk XOR-swizzled with (row >> 2) & 3
+F5_DEVICE int lds_off2(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
+
+// Opt-in to more than 64 KiB of dynamic LDS.  The attribute is per device, so one bit per device ordinal is kept per kernel
+// (a process-wide flag left a second device's launches without the opt-in).
+static inline hipError_t f5_set_lds_attr(const void* fn, int bytes, unsigned& done_mask) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (done_mask >> (dev & 31) & 1u) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) done_mask |= 1u << (dev & 31);
+    return e;
+}
+
+template <int N>
+F5_DEVICE void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
 struct GemmArgs {
     const __bf16* A[2];
     int lda;
@@ -57,7 +75,7 @@ struct GemmArgs {
 // GUARD = false is the interior fast path (whole wave tile inside M x N, no column groups, no row_keep): straight-line code, so
 // the compiler counts vmcnt exactly -- all residual loads in flight, stores never waited on.  With per-row-group exec
 // branches (GUARD = true) it falls back to s_waitcnt vmcnt(0) per group, which serialises every store's latency.
-template <int ACT, int WN, int ROWS, bool RES, bool OUTF, int OUTS, bool GUARD>   // OUTS: 0 none, 1 split bf16, 2 one fp16 plane
+template <int ACT, int WN, int ROWS, bool RES, bool OUTF, int OUTS, bool GUARD, int SLD = WN>   // OUTS: 0 none, 1 split bf16, 2 one fp16 plane; SLD: row stride of `stg` in floats
 F5_DEVICE void epi_generic_rows_t(const GemmArgs& p, const float* stg, int m_base, int n_base, int lane) {
     constexpr int LPR = WN / 4, RPP = 64 / LPR, NQ = ROWS / RPP;
     const int c4 = (lane % LPR) * 4, r0 = lane / LPR;
@@ -90,7 +108,7 @@ F5_DEVICE void epi_generic_rows_t(const GemmArgs& p, const float* stg, int m_bas
     const size_t sf = (size_t)RPP * p.ldo, sb = (size_t)RPP * p.ldob;
 #pragma unroll
     for (int q = 0; q < NQ; q++) {
-        f32x4 v = *reinterpret_cast<const f32x4*>(stg + (q * RPP + r0) * WN + c4) + bv;
+        f32x4 v = *reinterpret_cast<const f32x4*>(stg + (q * RPP + r0) * SLD + c4) + bv;
         if (ACT != ACT_NONE) {
 #pragma unroll
             for (int e = 0; e < 4; e++) v[e] = apply_act(v[e], ACT);
@@ -113,40 +131,40 @@ F5_DEVICE void epi_generic_rows_t(const GemmArgs& p, const float* stg, int m_bas
     }
 }
 
-template <int ACT, int WN, int ROWS, bool GUARD>
+template <int ACT, int WN, int ROWS, bool GUARD, int SLD = WN>
 F5_DEVICE void epi_generic_rows_g(const GemmArgs& p, const float* stg, int m_base, int n_base, int lane) {
     const bool res = p.res != nullptr, outf = p.out_f32 != nullptr, outs = p.out_hi != nullptr;
     if (ACT == ACT_NONE) {   // residual / plain projections: every output combination occurs
         if (res) {
-            if (outf && outs) epi_generic_rows_t<ACT, WN, ROWS, true, true, 1, GUARD>(p, stg, m_base, n_base, lane);
-            else if (outf) epi_generic_rows_t<ACT, WN, ROWS, true, true, 0, GUARD>(p, stg, m_base, n_base, lane);
-            else epi_generic_rows_t<ACT, WN, ROWS, true, false, 1, GUARD>(p, stg, m_base, n_base, lane);
+            if (outf && outs) epi_generic_rows_t<ACT, WN, ROWS, true, true, 1, GUARD, SLD>(p, stg, m_base, n_base, lane);
+            else if (outf) epi_generic_rows_t<ACT, WN, ROWS, true, true, 0, GUARD, SLD>(p, stg, m_base, n_base, lane);
+            else epi_generic_rows_t<ACT, WN, ROWS, true, false, 1, GUARD, SLD>(p, stg, m_base, n_base, lane);
         } else {
-            if (outf && outs) epi_generic_rows_t<ACT, WN, ROWS, false, true, 1, GUARD>(p, stg, m_base, n_base, lane);
-            else if (outf) epi_generic_rows_t<ACT, WN, ROWS, false, true, 0, GUARD>(p, stg, m_base, n_base, lane);
-            else if (p.f16_out) epi_generic_rows_t<ACT, WN, ROWS, false, false, 2, GUARD>(p, stg, m_base, n_base, lane);
-            else epi_generic_rows_t<ACT, WN, ROWS, false, false, 1, GUARD>(p, stg, m_base, n_base, lane);
+            if (outf && outs) epi_generic_rows_t<ACT, WN, ROWS, false, true, 1, GUARD, SLD>(p, stg, m_base, n_base, lane);
+            else if (outf) epi_generic_rows_t<ACT, WN, ROWS, false, true, 0, GUARD, SLD>(p, stg, m_base, n_base, lane);
+            else if (p.f16_out) epi_generic_rows_t<ACT, WN, ROWS, false, false, 2, GUARD, SLD>(p, stg, m_base, n_base, lane);
+            else epi_generic_rows_t<ACT, WN, ROWS, false, false, 1, GUARD, SLD>(p, stg, m_base, n_base, lane);
         }
     } else {                 // activations: (no residual -> split or fp32) and (residual -> fp32) are the combinations in use
-        if (res) epi_generic_rows_t<ACT, WN, ROWS, true, true, 0, GUARD>(p, stg, m_base, n_base, lane);
-        else if (outs && !outf && p.f16_out) epi_generic_rows_t<ACT, WN, ROWS, false, false, 2, GUARD>(p, stg, m_base, n_base, lane);
-        else if (outs && !outf) epi_generic_rows_t<ACT, WN, ROWS, false, false, 1, GUARD>(p, stg, m_base, n_base, lane);
-        else if (outf && !outs) epi_generic_rows_t<ACT, WN, ROWS, false, true, 0, GUARD>(p, stg, m_base, n_base, lane);
-        else epi_generic_rows_t<ACT, WN, ROWS, false, true, 1, GUARD>(p, stg, m_base, n_base, lane);
+        if (res) epi_generic_rows_t<ACT, WN, ROWS, true, true, 0, GUARD, SLD>(p, stg, m_base, n_base, lane);
+        else if (outs && !outf && p.f16_out) epi_generic_rows_t<ACT, WN, ROWS, false, false, 2, GUARD, SLD>(p, stg, m_base, n_base, lane);
+        else if (outs && !outf) epi_generic_rows_t<ACT, WN, ROWS, false, false, 1, GUARD, SLD>(p, stg, m_base, n_base, lane);
+        else if (outf && !outs) epi_generic_rows_t<ACT, WN, ROWS, false, true, 0, GUARD, SLD>(p, stg, m_base, n_base, lane);
+        else epi_generic_rows_t<ACT, WN, ROWS, false, true, 1, GUARD, SLD>(p, stg, m_base, n_base, lane);
     }
 }
 
-template <int ACT, int WN, int ROWS>
+template <int ACT, int WN, int ROWS, int SLD = WN>
 F5_DEVICE void epi_generic_rows(const GemmArgs& p, const float* stg, int m_base, int n_base, int lane) {
     // wave-uniform: interior tile with both split planes (or none) and no per-row / per-group special cases
     const bool interior = m_base + ROWS <= p.M && n_base + WN <= p.N && !p.group_w && !p.row_keep && (!p.out_hi || p.out_lo || p.f16_out);
-    if (interior) epi_generic_rows_g<ACT, WN, ROWS, false>(p, stg, m_base, n_base, lane);
-    else epi_generic_rows_g<ACT, WN, ROWS, true>(p, stg, m_base, n_base, lane);
+    if (interior) epi_generic_rows_g<ACT, WN, ROWS, false, SLD>(p, stg, m_base, n_base, lane);
+    else epi_generic_rows_g<ACT, WN, ROWS, true, SLD>(p, stg, m_base, n_base, lane);
 }
 
 // Q / K blocks of the fused QKV projection: bias, rotary embedding on head 0 (x-transformers interleaved pairs, applied
 // before the head split: F/model/modules.py:414-419), q * 1/8 (softmax scale, exact in bf16), bf16 row-major [M][2 D]
-template <int WN, int ROWS, bool ROT, bool GUARD>
+template <int WN, int ROWS, bool ROT, bool GUARD, int SLD = WN>
 F5_DEVICE void epi_qk_rows_t(const GemmArgs& p, const float* stg, int m_base, int n_base, int lane) {
     constexpr int LPR = WN / 4, RPP = 64 / LPR, NQ = ROWS / RPP;
     const int c4 = (lane % LPR) * 4, r0 = lane / LPR;
@@ -170,7 +188,7 @@ F5_DEVICE void epi_qk_rows_t(const GemmArgs& p, const float* stg, int m_base, in
     __bf16* op = p.qk + (size_t)(m_base + r0) * (2 * D) + which * D + nd;
 #pragma unroll
     for (int q = 0; q < NQ; q++) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(stg + (q * RPP + r0) * WN + c4) + bv;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(stg + (q * RPP + r0) * SLD + c4) + bv;
         bf16x4 o;
         if (ROT) {
             // explicit product + fma: left to the compiler, the contraction of a*c - b*s differs between template instantiations (64- vs
@@ -187,16 +205,16 @@ F5_DEVICE void epi_qk_rows_t(const GemmArgs& p, const float* stg, int m_base, in
     }
 }
 
-template <int WN, int ROWS>
+template <int WN, int ROWS, int SLD = WN>
 F5_DEVICE void epi_qk_rows(const GemmArgs& p, const float* stg, int m_base, int n_base, int lane) {
     const int which = n_base / p.D;
     const bool rot = n_base - which * p.D < 64;   // head 0 only (wave-uniform)
     if (m_base + ROWS <= p.M) {
-        if (rot) epi_qk_rows_t<WN, ROWS, true, false>(p, stg, m_base, n_base, lane);
-        else epi_qk_rows_t<WN, ROWS, false, false>(p, stg, m_base, n_base, lane);
+        if (rot) epi_qk_rows_t<WN, ROWS, true, false, SLD>(p, stg, m_base, n_base, lane);
+        else epi_qk_rows_t<WN, ROWS, false, false, SLD>(p, stg, m_base, n_base, lane);
     } else {
-        if (rot) epi_qk_rows_t<WN, ROWS, true, true>(p, stg, m_base, n_base, lane);
-        else epi_qk_rows_t<WN, ROWS, false, true>(p, stg, m_base, n_base, lane);
+        if (rot) epi_qk_rows_t<WN, ROWS, true, true, SLD>(p, stg, m_base, n_base, lane);
+        else epi_qk_rows_t<WN, ROWS, false, true, SLD>(p, stg, m_base, n_base, lane);
     }
 }
 

@@ -1,0 +1,35 @@
+// Non-template entry points of the MFMA kernels.  Every kernel family is its own translation unit (tu_*.hip) so the library builds
+// in parallel and a kernel edit recompiles one unit; the host orchestration (f5hip.hip) sees only these declarations.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "attn_common.h"
+#include "gemm_epilogue.h"
+
+// gemm.h: register-staged 128 x {128, 64} x 32 kernel (prec 1 bf16, 2 split bf16, 3 fp16); conv = implicit-GEMM operand
+hipError_t f5_launch_gemm_reg(int prec, int bn, bool conv, int epi, const GemmArgs& a, int m_pad, int n_pad, hipStream_t st);
+// gemm3.h: warp-specialised LDS-DMA kernel, 128 x bn (128, or 256 for one-plane operands) x 32
+hipError_t f5_launch_gemm3(int prec, int epi, int bn, const GemmArgs& a, int m_pad, int n_pad, hipStream_t st);
+// gemm5.h: exact-fit (16 rb) x (16 cb) tiles, 64-deep k-steps, fp16 operands
+hipError_t f5_launch_gemm5_generic(const GemmArgs& a, int rb, int cb, int n_pad, hipStream_t st);
+hipError_t f5_launch_gemm5_qkv(const GemmArgs& a, int rb, int cb, int n_pad, hipStream_t st);
+// attn3.h: flash attention forward, 256 queries per workgroup
+hipError_t f5_launch_attn3(const AttnArgs& a, int max_len, int heads, int n_seq, hipStream_t st);
+
+// gemm5 tile choice: fewest operand bytes per CU over the whole launch = rounds on the 256 CUs x (BM + BN); ties -> the larger tile.
+// rb == 0: no instantiated tile divides n_pad.
+struct Gemm5Choice { int rb, cb; };
+static inline Gemm5Choice gemm5_choose(int m_rows, int n_pad) {
+    static const int rbs[2] = {11, 8}, cbs[3] = {4, 8, 12};
+    Gemm5Choice best = {0, 0};
+    double best_cost = 1e30;
+    for (int rb : rbs)
+        for (int cb : cbs) {
+            if (n_pad % (cb * 16)) continue;
+            const long long tiles = (long long)((m_rows + rb * 16 - 1) / (rb * 16)) * (n_pad / (cb * 16));
+            const double rounds = (double)((tiles + 255) / 256);
+            const double cost = rounds * (rb * 16 + cb * 16);
+            if (cost < best_cost - 1e-9 || (cost < best_cost + 1e-9 && rb * cb > best.rb * best.cb)) { best_cost = cost; best = {rb, cb}; }
+        }
+    return best;
+}
