@@ -91,6 +91,30 @@ int f5hip_get_profile(const char* kernel_class, double* total_ms, int64_t* launc
  * name "reset" zeroes all of them (value may be NULL). */
 int f5hip_get_counter(const char* name, int64_t* value);
 
+/* ---------------------------------------------------------------- per-kernel unit ops ----------------- */
+/* One production kernel each, fp32 device tensors in and out, through the same dispatcher the sampler uses (SURVEY section 8(b)-4:
+ * "per-kernel ops for unit parity").  They allocate their operand planes per call: test / tooling entry points, not the hot path.
+ *
+ * f5hip_op_gemm: out = (act(A W^T + bias), rows with row_keep == 0 zeroed) * mul + res   -- nn.Linear + the fused epilogue of
+ *   Attention.to_out / FeedForward (F/model/modules.py:324-328,441-447,566-571).
+ *   a_dev [M][K], w_dev [N][K] (nn.Linear layout), bias_dev [N] | NULL, mul_dev [N] | NULL (AdaLN gate), res_dev [M][N] | NULL,
+ *   row_keep_host uint8 [M] | NULL (host); prec 1 = bf16, 2 = split bf16 (bf16x3), 3 = fp16 operands, fp32 accumulate;
+ *   act 0 none, 1 GELU(tanh), 2 GELU(erf), 3 Mish, 4 SiLU.  out_dev fp32 [M][N], or out16_dev: one fp16 plane [M][N] (the operand the
+ *   next fp16 GEMM reads; saturates at +-65504).  iters > 0: also times `iters` launches with HIP events on `stream`, cycling through
+ *   w_copies copies of the packed weights (a pool larger than the Infinity Cache makes them HBM-cold as in the real forward). */
+int f5hip_op_gemm(int32_t M, int32_t N, int32_t K, const float* a_dev, const float* w_dev, const float* bias_dev, int32_t prec,
+                  int32_t act, const float* mul_dev, const float* res_dev, const uint8_t* row_keep_host, float* out_dev,
+                  uint16_t* out16_dev, int32_t w_copies, int32_t iters, double* avg_us, void* stream);
+/* f5hip_op_qkv: fused to_q | to_k | to_v projection with its epilogue: bias, rotary embedding on channels 0..63 (head 0, interleaved
+ *   pairs) of q and k, q / 8, V transposed (F/model/modules.py:409-426).  a_dev [M][D], w_dev [3 D][D], bias_dev [3 D], row_pos host
+ *   int32 [M] (rotary position of every row, 0..4096); outputs bf16: qk_dev [ceil128(M)][2 D], vt_dev [D][ceil128(M)]. */
+int f5hip_op_qkv(int32_t M, int32_t D, const float* a_dev, const float* w_dev, const float* bias_dev, const int32_t* row_pos,
+                 int32_t prec, uint16_t* qk_dev, uint16_t* vt_dev, int32_t iters, double* avg_us, void* stream);
+/* f5hip_op_layernorm: y = LN(x) * (gain_off + scale) + shift (AdaLN: gain_off 1; affine LN: gain_off 0; F/model/modules.py:285-290),
+ *   rms = 1: x-transformers RMSNorm y = x / max(|x|_2, 1e-12) * sqrt(D) * scale.  All fp32 [M][D] / [D]. */
+int f5hip_op_layernorm(int32_t M, int32_t D, const float* x_dev, const float* scale_dev, const float* shift_dev, float gain_off, float eps,
+                       int32_t rms, float* out_dev, void* stream);
+
 /* ---------------------------------------------------------------- Vocos vocoder ----------------------- */
 
 typedef struct f5hip_vocos_config {

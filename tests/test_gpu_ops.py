@@ -1,0 +1,179 @@
+"""GPU parity of the per-kernel unit ops (include/f5hip.h "unit ops"): every hot kernel alone, through the C ABI, against a
+plain fp64 torch reference of the same op evaluated on the operand values the kernel actually multiplies (fp16 / bf16 /
+split-bf16 rounding of the inputs), so the tolerance only has to cover the fp32 accumulation order: 2e-5 relative rms.
+Shapes are the transformer-block GEMMs of F5-TTS-Base at the BASELINE configs (M = 2816 rows = one 10 s utterance with both CFG
+branches; F/model/modules.py:324-328,409-447) plus ragged / partial-tile / short-K edge cases."""
+import ctypes as C
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _counter(name):
+    from tts_indic_server_f5_amd import _lib
+    v = C.c_int64(0)
+    _lib.check(_lib.lib().f5hip_get_counter(name.encode(), C.byref(v)), "get_counter")
+    return v.value
+
+
+def _reset_counters():
+    from tts_indic_server_f5_amd import _lib
+    _lib.check(_lib.lib().f5hip_get_counter(b"reset", None), "reset counters")
+
+
+def _operand_values(x, prec):
+    """fp64 tensors whose products sum to what the kernel multiplies: [(a_part, w_part_selector)]."""
+    if prec == 3:
+        return x.half().double(), None
+    hi = x.bfloat16()
+    if prec == 1:
+        return hi.double(), None
+    lo = (x - hi.float()).bfloat16()
+    return hi.double(), lo.double()
+
+
+def _ref_matmul(a, w, prec):
+    ah, al = _operand_values(a, prec)
+    wh, wl = _operand_values(w, prec)
+    y = ah @ wh.T
+    if prec == 2:   # bf16x3: hi*hi + hi*lo + lo*hi (the lo*lo term is dropped by design)
+        y = y + ah @ wl.T + al @ wh.T
+    return y
+
+
+def _act(y, act):
+    if act == "gelu_tanh":
+        return torch.nn.functional.gelu(y, approximate="tanh")
+    if act == "gelu_erf":
+        return torch.nn.functional.gelu(y)
+    if act == "silu":
+        return torch.nn.functional.silu(y)
+    if act == "mish":
+        return torch.nn.functional.mish(y)
+    return y
+
+
+def _rel(got, ref):
+    return ((got.double().cpu() - ref.cpu()).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt().clamp_min(1e-30)).item()
+
+
+CASES = [
+    # (M, N, K, prec, act, bias, mul, res, row_keep, out16, expected counter)
+    (2816, 1024, 1024, 3, "none", True, True, True, False, False, "gemm5_rb11"),      # attention out-projection, C2 (176 x 64 tiles)
+    (2816, 1024, 2048, 3, "none", True, True, True, False, False, "gemm5_rb11"),      # FF2, C2
+    (2816, 2048, 1024, 3, "gelu_tanh", True, False, False, False, True, "gemm5_1x4"),  # FF1, C2: fp16 plane out (176 x 128 tiles)
+    (2816, 1024, 1024, 3, "none", True, False, True, True, False, "gemm5_rb11"),      # masked rows (padded-batch semantics)
+    (1404, 1024, 1024, 3, "none", True, True, True, False, False, None),               # M not a multiple of any tile height: partial row slab
+    (1536, 768, 768, 3, "none", True, True, True, False, False, "gemm5_rb8"),         # F5-Small widths (C1): 128-row tiles
+    (2816, 100, 1024, 3, "none", True, False, False, False, False, None),              # N = mel_dim: partial column panel
+    (2816, 1024, 128, 3, "silu", True, False, False, False, False, None),              # K shorter than the ring depth
+    (22528, 1024, 1024, 3, "none", True, True, True, False, False, "gemm5_1x4"),      # C3 share: 8 utterances x 2 branches (batch mode, 8 rounds)
+    (2816, 1024, 1024, 2, "none", True, True, True, False, False, None),               # bf16x3 (strict mode)
+    (2816, 2048, 1024, 1, "gelu_tanh", True, False, False, False, False, None),        # plain bf16
+    (200, 512, 1024, 2, "gelu_erf", True, False, False, False, False, None),           # Vocos-sized, erf GELU
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[f"M{c[0]}_N{c[1]}_K{c[2]}_p{c[3]}_{c[4]}{'_keep' if c[8] else ''}{'_f16out' if c[9] else ''}" for c in CASES])
+def test_gemm_unit_op(case):
+    from tts_indic_server_f5_amd import ops
+    M, N, K, prec, act, use_bias, use_mul, use_res, use_keep, out16, counter = case
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K + prec)
+    a = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    bias = torch.randn(N, generator=g) * 0.1 if use_bias else None
+    mul = torch.randn(N, generator=g) if use_mul else None
+    res = torch.randn(M, N, generator=g) if use_res else None
+    keep = (torch.rand(M, generator=g) > 0.3) if use_keep else None
+    ref = _ref_matmul(a, w, prec)
+    if bias is not None:
+        ref = ref + bias.double()
+    ref = _act(ref, act)
+    if keep is not None:
+        ref = ref * keep.double()[:, None]
+    if mul is not None:
+        ref = ref * mul.double()
+    if res is not None:
+        ref = ref + res.double()
+    _reset_counters()
+    out, _ = ops.gemm(a.to(DEV), w.to(DEV), bias, prec=prec, act=act, mul=mul, res=res, row_keep=keep, out16=out16)
+    if counter:
+        assert _counter(counter) == 1, f"{counter} path was not taken"
+    assert torch.isfinite(out).all()
+    if out16:
+        # one fp16 rounding of the output on top of the accumulation error
+        assert _rel(out.float(), ref) < 6e-4
+        assert (out.float().cpu() - ref.half().float()).abs().max() <= 2 * torch.finfo(torch.float16).eps * ref.abs().max()
+    else:
+        assert _rel(out, ref) < (3e-4 if act in ("gelu_tanh", "silu", "mish") else 2e-5)   # hardware exp2 / rcp in the activations: ~1 ulp each
+
+
+def test_gemm_f16_output_saturates():
+    """fp16 safety: a pre-activation beyond the fp16 range must come out as +-65504, never inf (a trained checkpoint with FF1 / GELU
+    outliers would otherwise poison the next GEMM's whole row with NaN)."""
+    from tts_indic_server_f5_amd import ops
+    g = torch.Generator().manual_seed(5)
+    a = torch.randn(256, 1024, generator=g)
+    w = torch.randn(1024, 1024, generator=g) / 32.0
+    a[3] *= 40000.0       # rows 3 and 77 produce |y| >> 65504
+    a[77] *= -90000.0
+    out, _ = ops.gemm(a.to(DEV), w.to(DEV), None, prec=2, act="none", out16=True)
+    assert torch.isfinite(out).all()
+    ref = (a.double() @ w.double().T).clamp(-65504.0, 65504.0)
+    assert out[3].float().abs().max().item() == 65504.0 and out[77].float().abs().max().item() == 65504.0
+    ok = torch.ones(256, dtype=torch.bool); ok[3] = ok[77] = False
+    assert _rel(out[ok].float(), ref[ok]) < 1e-3
+    big = ref[~ok].abs() >= 65504.0
+    assert (out[~ok].float().cpu().abs()[big] == 65504.0).all()
+
+
+@pytest.mark.parametrize("M,D,prec", [(2816, 1024, 3), (1404, 1024, 3), (1536, 768, 3), (2816, 1024, 2), (300, 256, 2)])
+def test_qkv_unit_op(M, D, prec):
+    """Fused QKV projection + epilogue against a reference that applies x-transformers' interleaved rotary embedding to channels
+    0..63 of q and k (head 0 only: F/model/modules.py:414-426), scales q by 1/8 and rounds to bf16 like the kernel's outputs."""
+    from oracle import dit_oracle as O
+    from tts_indic_server_f5_amd import ops
+    g = torch.Generator().manual_seed(M + D + prec)
+    a = torch.randn(M, D, generator=g)
+    w = torch.randn(3 * D, D, generator=g) / D ** 0.5
+    bias = torch.randn(3 * D, generator=g) * 0.1
+    pos = torch.arange(M) % 1405          # two sequences' worth of positions
+    y = (_ref_matmul(a, w, prec) + bias.double()).float()
+    q, k, v = y[:, :D].clone(), y[:, D:2 * D].clone(), y[:, 2 * D:]
+    freqs = O.rotary_freqs(1405, 64)[0][pos]           # [M, 64]
+    q[:, :64] = O.apply_rotary(q[None, :, :64], freqs[None])[0]
+    k[:, :64] = O.apply_rotary(k[None, :, :64], freqs[None])[0]
+    q = q * 0.125
+    _reset_counters()
+    gq, gk, gv, _ = ops.qkv(a.to(DEV), w.to(DEV), bias, pos.numpy(), prec=prec)
+    if prec == 3 and M == 2816:
+        assert _counter("gemm5_1x4") == 1 and _counter("gemm5_rb11") == 1
+    for name, got, ref in (("q", gq, q), ("k", gk, k), ("v", gv, v)):
+        err = (got.cpu() - ref.bfloat16().float()).abs()
+        # bf16 outputs: identical up to accumulation-order flips of the last bf16 bit on a few elements
+        assert err.max() <= 2.0 ** -7 * ref.abs().max(), name
+        assert (err > 0).float().mean() < 0.02, name
+        assert _rel(got, ref.double()) < 3e-3, name
+
+
+@pytest.mark.parametrize("rms", [False, True])
+def test_layernorm_unit_op(rms):
+    from tts_indic_server_f5_amd import ops
+    g = torch.Generator().manual_seed(9)
+    M, D = 2816, 1024
+    x = torch.randn(M, D, generator=g) * 3 + 0.5
+    scale = torch.randn(D, generator=g) * 0.3
+    shift = torch.randn(D, generator=g) * 0.3
+    xd = x.double()
+    if rms:
+        ref = xd / xd.norm(dim=-1, keepdim=True).clamp_min(1e-12) * D ** 0.5 * scale.double()
+        out = ops.layernorm(x.to(DEV), scale, torch.zeros(D), gain_off=0.0, eps=0.0, rms=True)
+    else:
+        mu, var = xd.mean(-1, keepdim=True), xd.var(-1, unbiased=False, keepdim=True)
+        ref = (xd - mu) / (var + 1e-6).sqrt() * (1 + scale.double()) + shift.double()
+        out = ops.layernorm(x.to(DEV), scale, shift, gain_off=1.0, eps=1e-6)
+    assert _rel(out, ref) < 2e-6

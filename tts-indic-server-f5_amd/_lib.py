@@ -44,6 +44,11 @@ SYMBOLS = {
     "f5hip_set_profiling": (C.c_int, [C.c_int32]),
     "f5hip_get_profile": (C.c_int, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "f5hip_get_counter": (C.c_int, [C.c_char_p, C.POINTER(C.c_int64)]),
+    "f5hip_op_gemm": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.c_void_p]),
+    "f5hip_op_qkv": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
+                               C.POINTER(C.c_double), C.c_void_p]),
+    "f5hip_op_layernorm": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int32, C.c_void_p, C.c_void_p]),
     "f5hip_vocos_create": (C.c_void_p, [C.POINTER(VocosConfig)]),
     "f5hip_vocos_destroy": (None, [C.c_void_p]),
     "f5hip_vocos_load_param": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]),

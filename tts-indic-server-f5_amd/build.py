@@ -65,6 +65,8 @@ def _compile(unit: str, flags: list[str], verbose: bool):
 def build(force: bool = False, verbose: bool = True, experiments: bool = False) -> str:
     os.makedirs(OBJ, exist_ok=True)
     flags = ["-DF5HIP_EXPERIMENTS"] if experiments else []
+    if os.environ.get("F5HIP_BUILD_ABL"):   # ablation variants of gemm5 (diagnostics): F5HIP_GEMM5_ABL=<n> then selects one at run time
+        flags.append("-DF5HIP_GEMM5_ABL")
     stamp = os.path.join(OBJ, "flags.txt")
     if not os.path.exists(stamp) or open(stamp).read() != " ".join(flags):
         force = True

@@ -30,11 +30,16 @@ F5_DEVICE void split_bf16x4(const float* y, bf16x4& hi, bf16x4& lo) {
     }
 }
 
-// fp32 x 4 -> fp16 x 4 (round to nearest even), stored through a 2-byte-element pointer shared with the bf16 planes
+// fp32 -> fp16 with saturation at the largest finite fp16 (one v_med3_f32): the reference runs these activations in fp32
+// (F/infer/utils_infer.py:176-184 -- the fp16 branch there is commented out), so an outlier beyond 65504 must degrade to a clamp,
+// never to inf (inf x 0 = NaN would poison the whole output row of the next GEMM).  NaN stays NaN.
+F5_DEVICE _Float16 sat_f16(float x) { return (_Float16)__builtin_fminf(__builtin_fmaxf(x, -65504.0f), 65504.0f); }
+
+// fp32 x 4 -> fp16 x 4 (round to nearest even, saturating), stored through a 2-byte-element pointer shared with the bf16 planes
 F5_DEVICE void store_f16x4(__bf16* dst, const float* y) {
     f16x4 h;
 #pragma unroll
-    for (int e = 0; e < 4; e++) h[e] = (_Float16)y[e];
+    for (int e = 0; e < 4; e++) h[e] = sat_f16(y[e]);
     *reinterpret_cast<f16x4*>(dst) = h;
 }
 

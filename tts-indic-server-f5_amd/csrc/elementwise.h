@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* w, int R,
     for (int c = threadIdx.x; c < C_pad; c += 256) {
         float v = (r < R && c < C) ? w[(size_t)r * ldw + c] : 0.0f;
         if (!lo) {
-            reinterpret_cast<_Float16*>(hi)[(size_t)r * C_pad + c] = (_Float16)v;
+            reinterpret_cast<_Float16*>(hi)[(size_t)r * C_pad + c] = sat_f16(v);
             continue;
         }
         __bf16 h, l;

@@ -275,8 +275,9 @@ int f5hip_dit_finalize(f5hip_dit* m) {
     }
     // --- rotary tables (x-transformers 2.2.8 RotaryEmbedding): angle = pos * 10000^(-2i/64) in fp32 ---
     {
-        std::vector<float> rc((size_t)4096 * 32), rs((size_t)4096 * 32);
-        for (int pos = 0; pos < 4096; pos++)
+        // 4097 rows: UNetT puts the time token at position 0, so a 4096-frame sequence reaches position 4096 (unett.py:184-188)
+        std::vector<float> rc((size_t)4097 * 32), rs((size_t)4097 * 32);
+        for (int pos = 0; pos < 4097; pos++)
             for (int i = 0; i < 32; i++) {
                 float inv = 1.0f / powf(10000.0f, (float)(2 * i) / 64.0f);
                 float ang = (float)pos * inv;
@@ -859,6 +860,7 @@ int f5hip_cfm_sample(f5hip_dit* m, int32_t n_utt, const int32_t* dur, const floa
 
 #include "vocos.h"
 #include "bigvgan.h"
+#include "unit_ops.h"
 #ifdef F5HIP_EXPERIMENTS
 #include "experiments/debug_bench.h"
 #endif

@@ -1,0 +1,179 @@
+// Per-kernel unit operators of the C ABI (include/f5hip.h, "unit ops"): each runs ONE production kernel through the same dispatcher the
+// sampler uses, on fp32 device tensors, so that `pytest -m gpu` can pin every hot kernel against a plain fp32 reference and the
+// tools can time it in isolation.  Included at the end of f5hip.hip (same translation unit as the dispatcher).
+#pragma once
+
+struct OpBufs {
+    std::vector<void*> ptrs;
+    ~OpBufs() { for (void* p : ptrs) if (p) (void)hipFree(p); }
+    template <typename T> T* get(size_t n) {
+        void* p = nullptr;
+        if (hipMalloc(&p, n * sizeof(T)) != hipSuccess) return nullptr;
+        ptrs.push_back(p);
+        return (T*)p;
+    }
+};
+
+// device fp32 [R][C] -> operand planes [R_pad][C] (prec 3: one fp16 plane; 2: split bf16; 1: bf16 hi only is read)
+static void op_pack_planes(const float* src, int R, int C, int R_pad, __bf16* hi, __bf16* lo, bool f16, hipStream_t st) {
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(R_pad), dim3(256), 0, st, src, R, C, C, hi, f16 ? (__bf16*)nullptr : lo, C);
+}
+
+extern "C" int f5hip_op_gemm(int32_t M, int32_t N, int32_t K, const float* a_dev, const float* w_dev, const float* bias_dev, int32_t prec,
+                             int32_t act, const float* mul_dev, const float* res_dev, const uint8_t* row_keep_host, float* out_dev,
+                             uint16_t* out16_dev, int32_t w_copies, int32_t iters, double* avg_us, void* stream) {
+    if (M <= 0 || N <= 0 || K <= 0 || K % 32 || N % 4 || !a_dev || !w_dev || prec < 1 || prec > 3 || (!out_dev && !out16_dev))
+        return fail(-1, "op_gemm: bad argument (need K %% 32 == 0, N %% 4 == 0, prec 1..3)");
+    if (out16_dev && (res_dev || out_dev)) return fail(-1, "op_gemm: the 16-bit output is the (no residual, no fp32 output) epilogue");
+    hipStream_t st = (hipStream_t)stream;
+    const int M_pad = (M + 127) / 128 * 128, N_pad = (N + 127) / 128 * 128;
+    const bool f16 = prec == 3;
+    if (w_copies < 1) w_copies = 1;
+    OpBufs b;
+    Plane2 A;
+    A.hi = b.get<__bf16>((size_t)M_pad * K); A.lo = b.get<__bf16>((size_t)M_pad * K);
+    float* bias = b.get<float>(N_pad);
+    int* keep = nullptr;
+    if (!A.hi || !A.lo || !bias) return fail(-5, "op_gemm: hipMalloc");
+    std::vector<PackedW> Ws(w_copies);
+    for (auto& W : Ws) {
+        W.hi = b.get<__bf16>((size_t)N_pad * K); W.lo = f16 ? nullptr : b.get<__bf16>((size_t)N_pad * K);
+        if (!W.hi || (!f16 && !W.lo)) return fail(-5, "op_gemm: hipMalloc weights");
+        W.n = N; W.k = K; W.n_pad = N_pad; W.k_pad = K; W.ld = K; W.bias = bias; W.f16 = f16;
+        op_pack_planes(w_dev, N, K, N_pad, W.hi, W.lo, f16, st);
+    }
+    op_pack_planes(a_dev, M, K, M_pad, A.hi, A.lo, f16, st);
+    (void)hipMemsetAsync(bias, 0, sizeof(float) * N_pad, st);
+    if (bias_dev) (void)hipMemcpyAsync(bias, bias_dev, sizeof(float) * N, hipMemcpyDeviceToDevice, st);
+    if (row_keep_host) {
+        keep = b.get<int>(M_pad);
+        std::vector<int> hk(M_pad, 0);
+        for (int i = 0; i < M; i++) hk[i] = row_keep_host[i];
+        if (!keep || hipMemcpyAsync(keep, hk.data(), sizeof(int) * M_pad, hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+            return fail(-6, "op_gemm: row_keep upload");
+    }
+    auto args_for = [&](const PackedW& W) {
+        GemmArgs g = gemm_base(A, K, W, M);
+        g.act = act; g.mul = mul_dev; g.res = res_dev; g.ldres = N; g.row_keep = keep;
+        if (out16_dev) { g.out_hi = (__bf16*)out16_dev; g.ldob = N; g.f16_out = 1; }
+        else { g.out_f32 = out_dev; g.ldo = N; }
+        return g;
+    };
+    {
+        GemmArgs g = args_for(Ws[0]);
+        CK(run_gemm_n(prec, M_pad, g, Ws[0], EPI_GENERIC, false, 128, st));
+    }
+    if (getenv("F5HIP_GEMM5_STAMPS")) {
+        // diagnostics (-DF5HIP_GEMM5_ABL builds, F5HIP_GEMM5_ABL=5): s_memrealtime stamps (100 MHz) of wave 0 (consumer) and wave 4 (loader) of every workgroup
+        const int maxg = 4096;
+        unsigned long long* d = b.get<unsigned long long>((size_t)maxg * 16);
+        if (d) {
+            (void)hipMemsetAsync(d, 0, sizeof(unsigned long long) * maxg * 16, st);
+            for (int rep = 0; rep < 3; rep++) {
+                GemmArgs g = args_for(Ws[rep % w_copies]);
+                g.stamps = d;
+                CK(run_gemm_n(prec, M_pad, g, Ws[rep % w_copies], EPI_GENERIC, false, 128, st));
+            }
+            (void)hipStreamSynchronize(st);
+            std::vector<unsigned long long> h((size_t)maxg * 16);
+            (void)hipMemcpy(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost);
+            unsigned long long tmin = ~0ull, tmax = 0;
+            int ng = 0;
+            for (int g2 = 0; g2 < maxg; g2++) if (h[(size_t)g2 * 16]) { ng = g2 + 1; tmin = std::min(tmin, h[(size_t)g2 * 16]); tmax = std::max(tmax, std::max(h[(size_t)g2 * 16 + 6], h[(size_t)g2 * 16 + 14])); }
+            const char* names[7] = {"start", "tile0 landed (loader)", "k-loop end", "E1 passed", "E2 passed (slab done)", "row phase issued", "stores drained"};
+            fprintf(stderr, "[gemm5 stamps] M %d N %d K %d: %d workgroups, first start -> last end %.2f us\n", M, N, K, ng, (tmax - tmin) * 0.01);
+            for (int w = 0; w < 2; w++)
+                for (int i = 0; i < 7; i++) {
+                    std::vector<double> v;
+                    for (int g2 = 0; g2 < ng; g2++) { const unsigned long long t = h[(size_t)g2 * 16 + w * 8 + i]; if (t) v.push_back((t - tmin) * 0.01); }
+                    if (v.empty()) continue;
+                    std::sort(v.begin(), v.end());
+                    fprintf(stderr, "[gemm5 stamps]   wave %d  %-26s min %6.2f  median %6.2f  max %6.2f us after the first workgroup started\n", w * 4, names[i], v.front(), v[v.size() / 2], v.back());
+                }
+        }
+    }
+    if (iters > 0 && avg_us) {
+        // timing: the residual epilogue accumulates in place, so time into a scratch output
+        float* scratch = b.get<float>((size_t)M * N);
+        if (!scratch) return fail(-5, "op_gemm: hipMalloc scratch");
+        hipEvent_t e0, e1;
+        (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+        for (int it = -3; it < iters; it++) {
+            if (it == 0) (void)hipEventRecord(e0, st);
+            const PackedW& W = Ws[(it + 3) % w_copies];
+            GemmArgs g = args_for(W);
+            if (!out16_dev) { g.out_f32 = scratch; if (res_dev) g.res = scratch; }
+            CK(run_gemm_n(prec, M_pad, g, W, EPI_GENERIC, false, 128, st));
+        }
+        (void)hipEventRecord(e1, st);
+        (void)hipEventSynchronize(e1);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        *avg_us = (double)ms * 1e3 / iters;
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    }
+    if (hipStreamSynchronize(st) != hipSuccess) return fail(-7, "op_gemm: %s", hipGetErrorString(hipGetLastError()));
+    return 0;
+}
+
+// Fused QKV projection with its epilogue (bias, rotary on head 0, q / 8, V transposed): F/model/modules.py:409-426.
+//   a_dev fp32 [M][D], w_dev fp32 [3 D][D] (to_q | to_k | to_v rows), bias_dev [3 D], row_pos host int32 [M]
+//   qk_dev  bf16 [M_pad][2 D] (q pre-scaled by 1/8 | k), vt_dev bf16 [D][M_pad], M_pad = ceil128(M)
+extern "C" int f5hip_op_qkv(int32_t M, int32_t D, const float* a_dev, const float* w_dev, const float* bias_dev, const int32_t* row_pos,
+                            int32_t prec, uint16_t* qk_dev, uint16_t* vt_dev, int32_t iters, double* avg_us, void* stream) {
+    if (M <= 0 || D <= 0 || D % 128 || !a_dev || !w_dev || !bias_dev || !row_pos || !qk_dev || !vt_dev || prec < 1 || prec > 3)
+        return fail(-1, "op_qkv: bad argument (need D %% 128 == 0)");
+    hipStream_t st = (hipStream_t)stream;
+    const int M_pad = (M + 127) / 128 * 128, N = 3 * D, N_pad = (N + 127) / 128 * 128;
+    const bool f16 = prec == 3;
+    OpBufs b;
+    Plane2 A; PackedW W;
+    A.hi = b.get<__bf16>((size_t)M_pad * D); A.lo = b.get<__bf16>((size_t)M_pad * D);
+    W.hi = b.get<__bf16>((size_t)N_pad * D); W.lo = f16 ? nullptr : b.get<__bf16>((size_t)N_pad * D);
+    float* bias = b.get<float>(N_pad);
+    float* rc = b.get<float>((size_t)4097 * 32); float* rs = b.get<float>((size_t)4097 * 32);
+    int* pos = b.get<int>(M_pad);
+    if (!A.hi || !A.lo || !W.hi || (!f16 && !W.lo) || !bias || !rc || !rs || !pos) return fail(-5, "op_qkv: hipMalloc");
+    W.n = N; W.k = D; W.n_pad = N_pad; W.k_pad = D; W.ld = D; W.bias = bias; W.f16 = f16;
+    std::vector<float> hc((size_t)4097 * 32), hs((size_t)4097 * 32);
+    for (int p = 0; p < 4097; p++)
+        for (int i = 0; i < 32; i++) {
+            const float ang = (float)p * (1.0f / powf(10000.0f, (float)(2 * i) / 64.0f));
+            hc[(size_t)p * 32 + i] = (float)cos((double)ang); hs[(size_t)p * 32 + i] = (float)sin((double)ang);
+        }
+    std::vector<int> hp(M_pad, 0);
+    for (int i = 0; i < M; i++) { if (row_pos[i] < 0 || row_pos[i] > 4096) return fail(-1, "op_qkv: row_pos out of range"); hp[i] = row_pos[i]; }
+    if (hipMemcpyAsync(rc, hc.data(), hc.size() * 4, hipMemcpyHostToDevice, st) != hipSuccess || hipMemcpyAsync(rs, hs.data(), hs.size() * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipMemcpyAsync(pos, hp.data(), hp.size() * 4, hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+        return fail(-6, "op_qkv: table upload");
+    op_pack_planes(w_dev, N, D, N_pad, W.hi, W.lo, f16, st);
+    op_pack_planes(a_dev, M, D, M_pad, A.hi, A.lo, f16, st);
+    (void)hipMemsetAsync(bias, 0, sizeof(float) * N_pad, st);
+    (void)hipMemcpyAsync(bias, bias_dev, sizeof(float) * N, hipMemcpyDeviceToDevice, st);
+    GemmArgs g = gemm_base(A, D, W, M);
+    g.D = D; g.row_pos = pos; g.rope_cos = rc; g.rope_sin = rs; g.qk = (__bf16*)qk_dev; g.vt = (__bf16*)vt_dev; g.ldvt = M_pad;
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    for (int it = -1; it < iters; it++) {
+        if (it == 0) (void)hipEventRecord(e0, st);
+        CK(run_gemm_n(prec, M_pad, g, W, EPI_QKV, false, 128, st));
+    }
+    (void)hipEventRecord(e1, st);
+    (void)hipEventSynchronize(e1);
+    if (iters > 0 && avg_us) { float ms = 0.f; (void)hipEventElapsedTime(&ms, e0, e1); *avg_us = (double)ms * 1e3 / iters; }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (hipStreamSynchronize(st) != hipSuccess) return fail(-7, "op_qkv: %s", hipGetErrorString(hipGetLastError()));
+    return 0;
+}
+
+// LayerNorm + modulation y = LN(x) (gain_off + scale) + shift (F/model/modules.py:285-290), or x-transformers RMSNorm (rms = 1): fp32 in, fp32 out
+extern "C" int f5hip_op_layernorm(int32_t M, int32_t D, const float* x_dev, const float* scale_dev, const float* shift_dev, float gain_off, float eps,
+                                  int32_t rms, float* out_dev, void* stream) {
+    if (M <= 0 || D <= 0 || D % 4 || !x_dev || !scale_dev || !shift_dev || !out_dev) return fail(-1, "op_layernorm: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    LnArgs ln; memset(&ln, 0, sizeof(ln));
+    ln.x = x_dev; ln.ldx = D; ln.M = M; ln.D = D; ln.scale = scale_dev; ln.shift = shift_dev; ln.gain_off = gain_off; ln.eps = eps; ln.rms = rms;
+    ln.out_f32 = out_dev; ln.ldof = D;
+    CK(run_ln(ln, st));
+    return 0;
+}

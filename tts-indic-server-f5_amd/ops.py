@@ -1,0 +1,64 @@
+"""Python face of the per-kernel unit ops of the C ABI (include/f5hip.h): one production HIP kernel each, fp32 torch
+tensors on the HIP device in and out.  Used by the per-kernel parity tests and the timing tools; not on the hot path."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+ACT = {"none": 0, "gelu_tanh": 1, "gelu_erf": 2, "mish": 3, "silu": 4}
+
+
+def _p(t):
+    if t is None:
+        return None
+    if isinstance(t, np.ndarray):
+        return C.c_void_p(t.ctypes.data)
+    return C.c_void_p(t.data_ptr())
+
+
+def _f32(t, dev):
+    return None if t is None else t.to(dev, torch.float32).contiguous()
+
+
+def gemm(a, w, bias=None, *, prec=3, act="none", mul=None, res=None, row_keep=None, out16=False, w_copies=1, iters=0):
+    """out = (act(a @ w.T + bias), masked rows zeroed) * mul + res.  Returns (out, avg_us); out is fp32 [M, N], or the fp16 plane."""
+    dev = a.device
+    M, K = a.shape
+    N = w.shape[0]
+    a, w, bias, mul, res = (_f32(t, dev) for t in (a, w, bias, mul, res))
+    out = torch.empty(M, N, device=dev, dtype=torch.float16 if out16 else torch.float32)
+    keep = None if row_keep is None else np.ascontiguousarray(row_keep.cpu().numpy().astype(np.uint8))
+    us = C.c_double(0.0)
+    _lib.check(_lib.lib().f5hip_op_gemm(M, N, K, _p(a), _p(w), _p(bias), prec, ACT[act], _p(mul), _p(res), _p(keep),
+                                        None if out16 else _p(out), _p(out) if out16 else None, w_copies, iters, C.byref(us),
+                                        _lib.current_stream_ptr()), "f5hip_op_gemm")
+    return out, us.value
+
+
+def qkv(a, w, bias, row_pos, *, prec=3, iters=0):
+    """Fused QKV projection + epilogue.  Returns (q [M, D] (already / 8), k [M, D], v [M, D]) as fp32 views of the bf16 outputs, avg_us."""
+    dev = a.device
+    M, D = a.shape
+    M_pad = (M + 127) // 128 * 128
+    a, w, bias = (_f32(t, dev) for t in (a, w, bias))
+    qk = torch.zeros(M_pad, 2 * D, device=dev, dtype=torch.bfloat16)
+    vt = torch.zeros(D, M_pad, device=dev, dtype=torch.bfloat16)
+    pos = np.ascontiguousarray(np.asarray(row_pos, dtype=np.int32))
+    us = C.c_double(0.0)
+    _lib.check(_lib.lib().f5hip_op_qkv(M, D, _p(a), _p(w), _p(bias), _p(pos), prec, _p(qk), _p(vt), iters, C.byref(us),
+                                       _lib.current_stream_ptr()), "f5hip_op_qkv")
+    return qk[:M, :D].float(), qk[:M, D:].float(), vt[:, :M].t().float(), us.value
+
+
+def layernorm(x, scale, shift, *, gain_off=1.0, eps=1e-6, rms=False):
+    dev = x.device
+    M, D = x.shape
+    x, scale, shift = (_f32(t, dev) for t in (x, scale, shift))
+    out = torch.empty_like(x)
+    _lib.check(_lib.lib().f5hip_op_layernorm(M, D, _p(x), _p(scale), _p(shift), float(gain_off), float(eps), int(rms), _p(out),
+                                             _lib.current_stream_ptr()), "f5hip_op_layernorm")
+    return out
