@@ -81,13 +81,22 @@ int f5hip_cfm_sample(f5hip_dit* m, int32_t n_utt, const int32_t* dur, const floa
                      const uint8_t* cond_mask, const int32_t* text, int32_t nt_max, const float* y0_dev,
                      const float* t_grid, int32_t steps, float cfg_strength, float* out_dev, void* stream);
 
+/* The same loop with the reference's PADDED-BATCH semantics (what CFM.sample does for batch > 1: F/model/cfm.py:151-154, mask =
+ * lens_to_mask(duration); F/model/modules.py:429-447): every item is laid out with dur[u] = the batch maximum, kv_len[u] = its own
+ * duration; keys >= kv_len[u] are masked in every attention, the attention output rows >= kv_len[u] are zeroed, and everything
+ * else (text / conv embeddings, feed-forward, the ODE update of the padded rows) runs over all dur[u] rows exactly like the
+ * reference's padded tensors.  kv_len == NULL is f5hip_cfm_sample. */
+int f5hip_cfm_sample_masked(f5hip_dit* m, int32_t n_utt, const int32_t* dur, const int32_t* kv_len, const float* cond_dev,
+                            const uint8_t* cond_mask, const int32_t* text, int32_t nt_max, const float* y0_dev,
+                            const float* t_grid, int32_t steps, float cfg_strength, float* out_dev, void* stream);
+
 /* Per-kernel timing of the last f5hip_cfm_sample call when profiling was enabled with
  * f5hip_set_profiling(1): average milliseconds per launch of the named kernel class
  * ("gemm", "attn", "ln", "other") measured with HIP events on the launch stream, and launch counts. */
 int f5hip_set_profiling(int32_t enabled);
 int f5hip_get_profile(const char* kernel_class, double* total_ms, int64_t* launches);
 /* Launch counters of the GEMM dispatcher since the last reset (test instrumentation: proves which kernel a config exercised):
- * "gemm5_rb11" / "gemm5_rb8" (exact-fit tile heights 176 / 128), "gemm5_1x4" (128- and 192-column tiles), "gemm3_wide";
+ * "gemm5_rb11" / "gemm5_rb8" (exact-fit tile heights 176 / 128), "gemm5_wide" (128- and 192-column tiles), "gemm3_wide";
  * name "reset" zeroes all of them (value may be NULL). */
 int f5hip_get_counter(const char* name, int64_t* value);
 

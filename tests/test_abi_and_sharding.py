@@ -98,3 +98,34 @@ def test_broadcast_and_gather_gloo_world2():
         p.join(timeout=60)
     assert all(ok for _, ok, _ in res), res
     assert sorted(res[0][2] + res[1][2]) == [0, 1, 2, 3, 4]
+
+
+def test_bench_launcher_spawns_one_rank_per_gpu():
+    """`python bench.py --gpus 2` (no torchrun environment) must start 2 fresh ranks itself, form the process group and report
+    n_gpus from its world size; F5HIP_BENCH_FAKE=1 skips the GPU work so this runs on CPU (gloo)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["F5HIP_BENCH_FAKE"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--mode", "strong"],
+                       env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["value"] == 3.0 and d["steps"] == 3 and d["mode"] == "strong"   # sum over ranks of (rank + 1)
+
+
+def test_strong_mode_sharding_covers_every_unit_once():
+    from tts_indic_server_f5_amd.sharding import shard_units, unit_cost
+    frames = [1404] * 64
+    for world in (1, 2, 4, 8):
+        sh = shard_units(frames, world)
+        assert sorted(sum(sh, [])) == list(range(64)) and {len(s) for s in sh} == {64 // world}
+    import random
+    rnd = random.Random(3)
+    ragged = [468 + rnd.randint(562, 1312) for _ in range(64)]          # U(6 s, 14 s) generated frames
+    sh = shard_units(ragged, 8)
+    loads = [sum(unit_cost(ragged[i]) for i in s) for s in sh]
+    assert sorted(sum(sh, [])) == list(range(64)) and max(loads) / min(loads) < 1.08   # LPT dealing balances the cost model

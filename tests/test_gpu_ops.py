@@ -65,13 +65,13 @@ CASES = [
     # (M, N, K, prec, act, bias, mul, res, row_keep, out16, expected counter)
     (2816, 1024, 1024, 3, "none", True, True, True, False, False, "gemm5_rb11"),      # attention out-projection, C2 (176 x 64 tiles)
     (2816, 1024, 2048, 3, "none", True, True, True, False, False, "gemm5_rb11"),      # FF2, C2
-    (2816, 2048, 1024, 3, "gelu_tanh", True, False, False, False, True, "gemm5_1x4"),  # FF1, C2: fp16 plane out (176 x 128 tiles)
+    (2816, 2048, 1024, 3, "gelu_tanh", True, False, False, False, True, "gemm5_wide"),  # FF1, C2: fp16 plane out (176 x 128 tiles)
     (2816, 1024, 1024, 3, "none", True, False, True, True, False, "gemm5_rb11"),      # masked rows (padded-batch semantics)
     (1404, 1024, 1024, 3, "none", True, True, True, False, False, None),               # M not a multiple of any tile height: partial row slab
     (1536, 768, 768, 3, "none", True, True, True, False, False, "gemm5_rb8"),         # F5-Small widths (C1): 128-row tiles
     (2816, 100, 1024, 3, "none", True, False, False, False, False, None),              # N = mel_dim: partial column panel
     (2816, 1024, 128, 3, "silu", True, False, False, False, False, None),              # K shorter than the ring depth
-    (22528, 1024, 1024, 3, "none", True, True, True, False, False, "gemm5_1x4"),      # C3 share: 8 utterances x 2 branches (batch mode, 8 rounds)
+    (22528, 1024, 1024, 3, "none", True, True, True, False, False, "gemm5_wide"),      # C3 share: 8 utterances x 2 branches (batch mode, 8 rounds)
     (2816, 1024, 1024, 2, "none", True, True, True, False, False, None),               # bf16x3 (strict mode)
     (2816, 2048, 1024, 1, "gelu_tanh", True, False, False, False, False, None),        # plain bf16
     (200, 512, 1024, 2, "gelu_erf", True, False, False, False, False, None),           # Vocos-sized, erf GELU
@@ -151,7 +151,7 @@ def test_qkv_unit_op(M, D, prec):
     _reset_counters()
     gq, gk, gv, _ = ops.qkv(a.to(DEV), w.to(DEV), bias, pos.numpy(), prec=prec)
     if prec == 3 and M == 2816:
-        assert _counter("gemm5_1x4") == 1 and _counter("gemm5_rb11") == 1
+        assert _counter("gemm5_wide") == 1 and _counter("gemm5_rb11") == 1
     for name, got, ref in (("q", gq, q), ("k", gk, k), ("v", gv, v)):
         err = (got.cpu() - ref.bfloat16().float()).abs()
         # bf16 outputs: identical up to accumulation-order flips of the last bf16 bit on a few elements

@@ -60,6 +60,18 @@ def test_infer_batch_process_glue(golden_dir, idx, amp):
 
 def test_text_to_tokens_rules():
     assert infer.text_to_tokens(["a;b“c”"]) == [list('a,b"c"')]
+    # the reference's space-before-a-multi-character-ASCII-segment rule (F/model/utils.py:153-156) under jieba's segmentation
+    # (known answers derived from jieba 0.42.1's published algorithm; the package is absent here: parity unpinned)
+    T = lambda s: "".join(infer.text_to_tokens([s])[0])
+    assert T("hello world") == "hello world"                 # a segment behind a space gets no second one
+    assert T("well-known") == "well- known"
+    assert T("(hello") == "( hello"
+    assert T("a,b2") == "a, b2"
+    assert T("x: yes 'no' \"ok\"") == "x: yes 'no' \"ok\""   # colon / quotes / space in front: no insertion
+    assert T("pi is 3.14 or 50%!") == "pi is 3.14 or 50%!"   # digits with a decimal part and a percent sign stay one segment
+    assert T("ಕ123 ಕabc") == "ಕ 123 ಕ abc"                  # ASCII run directly behind an Indic character
+    assert T("a...b") == "a ...b"                             # a run of dots is one (multi-character, ASCII) segment; the single "b" gets none
+    assert T("ಕನ್ನಡ ಪಠ್ಯ.") == "ಕನ್ನಡ ಪಠ್ಯ."
     with pytest.raises(NotImplementedError):
         infer.text_to_tokens(["中文"])
     assert infer.text_to_tokens(["ಕನ್ನಡ."]) == [list("ಕನ್ನಡ.")]

@@ -482,9 +482,9 @@ static int run_ln(const LnArgs& a, hipStream_t st) {
     return 0;
 }
 
-// Diagnostics for tests: which GEMM path the launches since the last reset took ("gemm5_rb11", "gemm5_rb8", "gemm5_1x4", "gemm3_wide"); name "reset" zeroes them.
+// Diagnostics for tests: which GEMM path the launches since the last reset took ("gemm5_rb11", "gemm5_rb8", "gemm5_wide", "gemm3_wide"); name "reset" zeroes them.
 extern "C" int f5hip_get_counter(const char* name, int64_t* value) {
-    static const char* names[4] = {"gemm5_rb11", "gemm5_rb8", "gemm5_1x4", "gemm3_wide"};
+    static const char* names[4] = {"gemm5_rb11", "gemm5_rb8", "gemm5_wide", "gemm3_wide"};
     if (!name) return fail(-1, "get_counter: null name");
     if (!strcmp(name, "reset")) { for (auto& c : g_counters) c = 0; return 0; }
     for (int i = 0; i < 4; i++)
@@ -818,6 +818,12 @@ int f5hip_dit_read_tap(f5hip_dit* m, const char* tap, float* dst_dev, int64_t nu
 int f5hip_cfm_sample(f5hip_dit* m, int32_t n_utt, const int32_t* dur, const float* cond_dev, const uint8_t* cond_mask,
                      const int32_t* text, int32_t nt_max, const float* y0_dev, const float* t_grid, int32_t steps,
                      float cfg_strength, float* out_dev, void* stream) {
+    return f5hip_cfm_sample_masked(m, n_utt, dur, nullptr, cond_dev, cond_mask, text, nt_max, y0_dev, t_grid, steps, cfg_strength, out_dev, stream);
+}
+
+int f5hip_cfm_sample_masked(f5hip_dit* m, int32_t n_utt, const int32_t* dur, const int32_t* kv_len, const float* cond_dev, const uint8_t* cond_mask,
+                            const int32_t* text, int32_t nt_max, const float* y0_dev, const float* t_grid, int32_t steps,
+                            float cfg_strength, float* out_dev, void* stream) {
     if (!m || !m->finalized) return fail(-1, "model not finalized");
     if (n_utt <= 0 || !dur || !cond_dev || !cond_mask || !text || !y0_dev || !t_grid || !out_dev || steps <= 0)
         return fail(-1, "cfm_sample: bad argument");
@@ -829,10 +835,12 @@ int f5hip_cfm_sample(f5hip_dit* m, int32_t n_utt, const int32_t* dur, const floa
     m->h_seq_len.clear();
     for (int u = 0; u < n_utt; u++) {
         if (dur[u] <= 0 || dur[u] > 4096) return fail(-1, "dur[%d] = %d out of range", u, dur[u]);
-        seqs.push_back({dur[u], dur[u], f0, u, 0, 0, 0});
+        const int kv = kv_len ? kv_len[u] : dur[u];
+        if (kv <= 0 || kv > dur[u]) return fail(-1, "kv_len[%d] = %d out of range (1..%d)", u, kv, dur[u]);
+        seqs.push_back({dur[u], kv, f0, u, 0, 0, 0});
         m->h_seq_len.push_back(dur[u]);
         if (use_cfg) {
-            seqs.push_back({dur[u], dur[u], f0, u, 1, 1, 1});
+            seqs.push_back({dur[u], kv, f0, u, 1, 1, 1});
             m->h_seq_len.push_back(dur[u]);
         }
         f0 += dur[u];

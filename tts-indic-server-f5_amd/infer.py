@@ -59,17 +59,52 @@ def chunk_text(text, max_chars=135):
 
 _CUSTOM_TRANS = str.maketrans({";": ",", "“": '"', "”": '"', "‘": "'", "’": "'"})   # F/model/utils.py:142-144
 
+# jieba 0.42.1 `cut(text)` (default mode, HMM on) restated for text WITHOUT CJK characters (third-party leaf, absent here: parity
+# unpinned, known-answer tests in tests/test_host_glue.py).  Its published algorithm: blocks matching re_han_default go to the
+# dictionary cutter, everything else is split at whitespace and yielded character by character; inside a block every character that
+# starts no dictionary word is buffered and the buffer goes through finalseg.cut, whose non-Han path splits at re_skip -- runs of
+# [a-zA-Z0-9]+(.digits)?%? stay whole and so do the runs of "+#&._%-" between them.  (jieba's dictionary holds a handful of entries
+# with Latin letters, e.g. "AT&T", "C++": those would come out as one segment there and as several here.)
+_RE_HAN_DEFAULT = re.compile(r"([\u4E00-\u9FD5a-zA-Z0-9+#&\._%\-]+)")
+_RE_SKIP_DEFAULT = re.compile(r"(\r\n|\s)")
+_RE_SKIP_FINAL = re.compile(r"([a-zA-Z0-9]+(?:\.\d+)?%?)")
+
+
+def _segments_non_cjk(text):
+    for blk in _RE_HAN_DEFAULT.split(text):
+        if not blk:
+            continue
+        if _RE_HAN_DEFAULT.match(blk):
+            if len(blk) == 1:
+                yield blk
+            else:
+                yield from (x for x in _RE_SKIP_FINAL.split(blk) if x)
+        else:
+            for x in _RE_SKIP_DEFAULT.split(blk):
+                if _RE_SKIP_DEFAULT.match(x):
+                    yield x
+                else:
+                    yield from x
+
 
 def text_to_tokens(text_list):
-    """Non-CJK subset of convert_char_to_pinyin (F/model/utils.py:140-177): translation table, then one token per
-    character.  (jieba's word segmentation only changes the output for CJK text and for the
-    space-before-a-Latin-word rule after CJK; neither applies to text without CJK characters.)"""
+    """convert_char_to_pinyin (F/model/utils.py:140-177) for text without CJK characters: translation table, jieba-style
+    segmentation, then the reference's rule per segment -- a pure-ASCII segment longer than one character gets a space in front
+    unless the previous token is one of space, colon, quote (:153-156), and is spelled out character by character; every other
+    segment (Indic scripts arrive one character per segment, and pypinyin returns non-Han characters unchanged) passes through
+    character by character.  CJK input is rejected instead of silently mis-tokenised (the pinyin front-end needs jieba's dictionary
+    and pypinyin's tables, which are not available offline)."""
     out = []
     for text in text_list:
         text = text.translate(_CUSTOM_TRANS)
-        if any("㄀" <= c <= "鿿" for c in text):
+        if any("\u3100" <= c <= "\u9fff" for c in text):
             raise NotImplementedError("CJK text needs the pinyin front-end (jieba/pypinyin), which is not on this path yet")
-        out.append(list(text))
+        chars = []
+        for seg in _segments_non_cjk(text):
+            if len(seg.encode("utf-8")) == len(seg) and chars and len(seg) > 1 and chars[-1] not in " :'\"":
+                chars.append(" ")
+            chars.extend(seg)
+        out.append(chars)
     return out
 
 
@@ -127,62 +162,80 @@ def infer_process(ref_audio, ref_text, gen_text, model_obj, vocoder, mel_spec_ty
                                speed=speed, fix_duration=fix_duration, device=device)
 
 
-def infer_batch_process(ref_audio, ref_text, gen_text_batches, model_obj, vocoder, mel_spec_type="vocos", progress=None,
-                        target_rms=0.1, cross_fade_duration=0.15, nfe_step=32, cfg_strength=2.0, sway_sampling_coef=-1,
-                        speed=1, fix_duration=None, device=None, tokenizer=text_to_tokens):
-    """F/infer/utils_infer.py:406-524."""
-    audio, sr = ref_audio
+def _prepare_reference(audio, sr, rms_floor, device):
+    """Prologue of infer_batch_process (F/infer/utils_infer.py:423-433): mono mix, gain up to `rms_floor`, resample to 24 kHz.
+    Returns (audio [1, nw] fp32, measured rms)."""
     if audio.shape[0] > 1:
         audio = torch.mean(audio, dim=0, keepdim=True)
     rms = torch.sqrt(torch.mean(torch.square(audio)))
-    if rms < target_rms:
-        audio = audio * target_rms / rms
+    if rms < rms_floor:
+        audio = audio * rms_floor / rms
     if sr != target_sample_rate:
         audio = resample_sinc_hann(audio, sr, target_sample_rate)
     if device is not None:
         audio = audio.to(device)
+    return audio, rms
 
-    generated_waves = []
-    spectrograms = []
+
+def plan_units(ref_text, gen_text_batches, ref_frames, speed=1.0, fix_duration=None, tokenizer=None):
+    """One sampling unit per text chunk: (tokens of ref_text + chunk, total frames).  Duration rule of the reference
+    (F/infer/utils_infer.py:446-454): UTF-8 byte lengths, `ref_frames = n_samples // hop` (one less than the mel has: SURVEY B2)."""
+    tokenizer = tokenizer or text_to_tokens
+    ref_bytes = len(ref_text.encode("utf-8"))
+    units = []
+    for chunk in gen_text_batches:
+        if fix_duration is not None:
+            frames = int(fix_duration * target_sample_rate / hop_length)
+        else:
+            frames = ref_frames + int(ref_frames / ref_bytes * len(chunk.encode("utf-8")) / speed)
+        units.append((tokenizer([ref_text + chunk])[0], frames))
+    return units
+
+
+def cross_fade_concat(waves, fade_seconds, sample_rate=target_sample_rate):
+    """Joins the chunk waveforms (F/infer/utils_infer.py:485-519): plain concatenation for a non-positive fade, else a linear
+    cross-fade over min(fade, len(prev), len(next)) samples.  The ramps are float64 (np.linspace), so the result is float64 from the
+    second chunk on, exactly like the reference's."""
+    if fade_seconds <= 0:
+        return np.concatenate(waves)
+    out = waves[0]
+    for nxt in waves[1:]:
+        n = min(int(fade_seconds * sample_rate), len(out), len(nxt))
+        if n <= 0:
+            out = np.concatenate([out, nxt])
+            continue
+        ramp = np.linspace(0, 1, n)
+        out = np.concatenate([out[:-n], out[-n:] * ramp[::-1] + nxt[:n] * ramp, nxt[n:]])
+    return out
+
+
+def infer_batch_process(ref_audio, ref_text, gen_text_batches, model_obj, vocoder, mel_spec_type="vocos", progress=None,
+                        target_rms=0.1, cross_fade_duration=0.15, nfe_step=32, cfg_strength=2.0, sway_sampling_coef=-1,
+                        speed=1, fix_duration=None, device=None, tokenizer=text_to_tokens):
+    """F/infer/utils_infer.py:406-524, same signature and return triple.
+
+    The reference loops over the chunks and calls `sample()` / the vocoder once per chunk with batch 1.  The chunks are independent
+    units, so here they are planned first and sampled in ONE `sample_units()` call when the model object offers it (F5HipModel: all
+    chunks packed back to back, each with the reference's batch-1 semantics, the reference-audio mel computed once instead of once
+    per chunk); any other object with the reference's `.sample()` is driven chunk by chunk like the reference does."""
+    audio, rms = _prepare_reference(*ref_audio, target_rms, device)
     if len(ref_text[-1].encode("utf-8")) == 1:
         ref_text = ref_text + " "
-    for gen_text in gen_text_batches:
-        final_text_list = tokenizer([ref_text + gen_text])
-        ref_audio_len = audio.shape[-1] // hop_length
-        if fix_duration is not None:
-            duration = int(fix_duration * target_sample_rate / hop_length)
-        else:
-            ref_text_len = len(ref_text.encode("utf-8"))
-            gen_text_len = len(gen_text.encode("utf-8"))
-            duration = ref_audio_len + int(ref_audio_len / ref_text_len * gen_text_len / speed)
-        generated, _ = model_obj.sample(cond=audio, text=final_text_list, duration=duration, steps=nfe_step,
-                                        cfg_strength=cfg_strength, sway_sampling_coef=sway_sampling_coef)
-        generated = generated.to(torch.float32)
-        generated = generated[:, ref_audio_len:, :]
-        generated_mel_spec = generated.permute(0, 2, 1)
-        if mel_spec_type == "vocos":
-            generated_wave = vocoder.decode(generated_mel_spec)
-        elif mel_spec_type == "bigvgan":
-            generated_wave = vocoder(generated_mel_spec)
-        else:
-            raise ValueError(mel_spec_type)
-        if rms < target_rms:
-            generated_wave = generated_wave * rms / target_rms
-        generated_waves.append(generated_wave.squeeze().cpu().numpy())
-        spectrograms.append(generated_mel_spec[0].cpu().numpy())
-
-    if cross_fade_duration <= 0:
-        final_wave = np.concatenate(generated_waves)
+    ref_frames = audio.shape[-1] // hop_length
+    units = plan_units(ref_text, gen_text_batches, ref_frames, speed, fix_duration, tokenizer)
+    knobs = dict(steps=nfe_step, cfg_strength=cfg_strength, sway_sampling_coef=sway_sampling_coef)
+    if hasattr(model_obj, "sample_units"):
+        mels = model_obj.sample_units(audio, units, **knobs)                       # list of [frames_i, mel] incl. the reference frames
     else:
-        final_wave = generated_waves[0]
-        for i in range(1, len(generated_waves)):
-            prev_wave, next_wave = final_wave, generated_waves[i]
-            n = min(int(cross_fade_duration * target_sample_rate), len(prev_wave), len(next_wave))
-            if n <= 0:
-                final_wave = np.concatenate([prev_wave, next_wave])
-                continue
-            fade_out = np.linspace(1, 0, n)   # float64 ramps: the result is float64 from the 2nd chunk on (SURVEY B10)
-            fade_in = np.linspace(0, 1, n)
-            mixed = prev_wave[-n:] * fade_out + next_wave[:n] * fade_in
-            final_wave = np.concatenate([prev_wave[:-n], mixed, next_wave[n:]])
-    return final_wave, target_sample_rate, np.concatenate(spectrograms, axis=1)
+        mels = [model_obj.sample(cond=audio, text=[tokens], duration=frames, **knobs)[0][0] for tokens, frames in units]
+    if mel_spec_type not in ("vocos", "bigvgan"):
+        raise ValueError(mel_spec_type)
+    waves, specs = [], []
+    for mel in mels:
+        spec = mel.to(torch.float32)[ref_frames:, :].t()[None]                     # strip the reference frames: [1, mel, T] (:468-470)
+        wave = vocoder.decode(spec) if mel_spec_type == "vocos" else vocoder(spec)
+        if rms < target_rms:
+            wave = wave * rms / target_rms
+        waves.append(wave.squeeze().cpu().numpy())
+        specs.append(spec[0].cpu().numpy())
+    return cross_fade_concat(waves, cross_fade_duration), target_sample_rate, np.concatenate(specs, axis=1)

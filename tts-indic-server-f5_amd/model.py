@@ -129,24 +129,44 @@ class F5HipModel:
         return out
 
     # ------------------------------------------------------------------ CFM.sample
+    def cond_mel(self, audio):
+        """The mel front-end CFM.sample applies to a raw-wave `cond` (F/model/cfm.py:103-106, modules.py:123-143): [b, nw] -> [b, n, mel].
+        infer_batch_process computes it once per request and hands the mel to every chunk (the reference recomputes it per chunk)."""
+        from .mel import mel_spectrogram, mel_spectrogram_bigvgan
+        fe = mel_spectrogram_bigvgan if self.mel_spec_type == "bigvgan" else mel_spectrogram
+        cond = fe(audio.to(self.device, torch.float32)).permute(0, 2, 1)
+        assert cond.shape[-1] == self.num_channels
+        return cond
+
+    @torch.no_grad()
+    def sample_units(self, audio, units, *, steps=32, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=None):
+        """All text chunks of one request in ONE sampler call (they are independent `sample()` calls in the reference,
+        F/infer/utils_infer.py:441-466).  `audio` [1, nw] reference wave (or its mel [1, n, mel]); `units` = [(tokens, frames)].
+        Returns one [frames_i, mel] tensor per unit.  Noise is drawn unit by unit in order, i.e. the same draws the reference's
+        sequential calls make from the global generator."""
+        cond = self.cond_mel(audio) if audio.ndim == 2 else audio.to(self.device, torch.float32)
+        b = len(units)
+        frames = torch.tensor([int(f) for _, f in units], dtype=torch.long)
+        out, _ = self.sample(cond.expand(b, -1, -1), [t for t, _ in units], frames, steps=steps, cfg_strength=cfg_strength,
+                             sway_sampling_coef=sway_sampling_coef, seed=seed)
+        # (sample() raises a duration to lens + 1 like the reference does, cfm.py:136: the rows of unit i are its FINAL duration)
+        return [out[i, :self._last_min_frames[i]] for i in range(b)]
+
     @torch.no_grad()
     def sample(self, cond, text, duration, *, lens=None, steps=32, cfg_strength=1.0, sway_sampling_coef=None,
                seed=None, max_duration=4096, vocoder=None, no_ref_audio=False, duplicate_test=False, t_inter=0.1,
-               edit_mask=None, y0=None):
+               edit_mask=None, y0=None, padded_batch=False):
         """CFM.sample (F/model/cfm.py:82-210).  Returns (out [b, n, mel] on the device, None): the trajectory is
         not materialised (its only in-tree consumer drops it, F/infer/utils_infer.py:459).
 
-        Every item of a batch is sampled with the reference's batch-1 semantics (mask=None, no padding), which
-        is what `infer_batch_process` uses; `y0` ([b, n, mel] or list of [dur_i, mel]) overrides the noise, which is
-        otherwise drawn exactly like the reference's CPU path (per item `torch.manual_seed(seed)`;
-        `torch.randn(dur, mel)` from the global CPU generator)."""
-        if duplicate_test:
-            raise NotImplementedError("duplicate_test is a debugging corner of the reference that is out of scope")
+        Batch semantics.  Default: every item is sampled with the reference's batch-1 semantics (mask=None, no padding) -- what
+        `infer_batch_process` uses, and independent of the batch composition.  `padded_batch=True` reproduces what the reference
+        computes when it is handed b > 1 items itself (cfm.py:151-154: every item padded to the longest, key-padding mask, zeroed
+        attention rows, unmasked convolutions over the padding), padded rows included.
+        `y0` ([b, n, mel] or list of [dur_i, mel]; host or device) overrides the noise, which is otherwise drawn exactly like the
+        reference's CPU path (per item `torch.manual_seed(seed)`; `torch.randn(dur, mel)` from the global CPU generator)."""
         if cond.ndim == 2:   # raw wave -> mel (cfm.py:103-106) with the extractor of mel_spec_type (modules.py:123-126)
-            from .mel import mel_spectrogram, mel_spectrogram_bigvgan
-            fe = mel_spectrogram_bigvgan if self.mel_spec_type == "bigvgan" else mel_spectrogram
-            cond = fe(cond.to(self.device, torch.float32)).permute(0, 2, 1)
-            assert cond.shape[-1] == self.num_channels
+            cond = self.cond_mel(cond)
         cond = cond.to(self.device, torch.float32)
         batch, cond_seq_len = cond.shape[:2]
         if lens is None:
@@ -166,41 +186,59 @@ class F5HipModel:
             duration = torch.full((batch,), duration, dtype=torch.long)
         duration = torch.maximum(lens + 1, duration.cpu()).clamp(max=max_duration)  # cfm.py:136-137
         nmax = int(duration.amax())
+        test_cond = None
+        if duplicate_test:   # cfm.py:139-141: the prompt mel repeated once right behind itself
+            test_cond = torch.nn.functional.pad(cond, (0, 0, cond_seq_len, nmax - 2 * cond_seq_len), value=0.0)
         cond = torch.nn.functional.pad(cond, (0, 0, 0, nmax - cond_seq_len), value=0.0)
         cond_mask = torch.nn.functional.pad(cond_mask, (0, nmax - cond_mask.shape[-1]), value=False)
 
-        # noise (cfm.py:181-186)
-        if y0 is None:
-            ys = []
-            for dur in duration:
+        durs = [int(d) for d in duration]
+        self._last_min_frames = durs
+        padded = bool(padded_batch) and batch > 1
+        lay = [nmax] * batch if padded else durs          # rows laid out per item
+
+        # noise (cfm.py:181-186): per item randn(dur_i), zero padded to the laid-out length
+        ys = []
+        for i, dur in enumerate(durs):
+            if y0 is None:
                 if seed is not None:
                     torch.manual_seed(seed)
-                ys.append(torch.randn(int(dur), self.num_channels))
-        else:
-            ys = [y0[i][: int(duration[i])].cpu().float() for i in range(batch)]
+                yi = torch.randn(dur, self.num_channels).to(self.device)
+            else:
+                yi = y0[i][:dur].to(self.device, torch.float32)
+            if lay[i] > dur:
+                yi = torch.nn.functional.pad(yi, (0, 0, 0, lay[i] - dur))
+            ys.append(yi)
 
-        t = torch.linspace(0, 1, steps + 1, dtype=torch.float32)                  # cfm.py:196-198
+        t_start = 0.0
+        if duplicate_test:   # cfm.py:190-194
+            t_start = float(t_inter)
+            ys = [(1 - t_start) * ys[i] + t_start * test_cond[i, :lay[i]] for i in range(batch)]
+            steps = int(steps * (1 - t_start))
+        t = torch.linspace(t_start, 1, steps + 1, dtype=torch.float32)            # cfm.py:196-198
         if sway_sampling_coef is not None:
             t = t + sway_sampling_coef * (torch.cos(torch.pi / 2 * t) - 1 + t)
 
-        durs = [int(d) for d in duration]
-        cond_packed = torch.cat([cond[i, :durs[i]] for i in range(batch)], dim=0).contiguous()
+        cond_packed = torch.cat([cond[i, :lay[i]] for i in range(batch)], dim=0).contiguous()
         mask_packed = np.ascontiguousarray(
-            torch.cat([cond_mask[i, :durs[i]] for i in range(batch)]).numpy().astype(np.uint8))
-        y0_packed = torch.cat(ys, dim=0).to(self.device).contiguous()
+            torch.cat([cond_mask[i, :lay[i]] for i in range(batch)]).numpy().astype(np.uint8))
+        y0_packed = torch.cat(ys, dim=0).contiguous()
         out_packed = torch.empty_like(y0_packed)
         text_np = _i32(text.numpy())
         tg = np.ascontiguousarray(t.numpy().astype(np.float32))
-        d_np = _i32(durs)
-        _lib.check(self._lib.f5hip_cfm_sample(
-            self._h, batch, _ptr(d_np), _ptr(cond_packed), _ptr(mask_packed), _ptr(text_np), text_np.shape[1],
-            _ptr(y0_packed), _ptr(tg), steps, float(cfg_strength), _ptr(out_packed), _lib.current_stream_ptr()),
+        d_np, kv_np = _i32(lay), _i32(durs)
+        _lib.check(self._lib.f5hip_cfm_sample_masked(
+            self._h, batch, _ptr(d_np), _ptr(kv_np) if padded else None, _ptr(cond_packed), _ptr(mask_packed), _ptr(text_np),
+            text_np.shape[1], _ptr(y0_packed), _ptr(tg), steps, float(cfg_strength), _ptr(out_packed), _lib.current_stream_ptr()),
             "f5hip_cfm_sample")
-        out = torch.zeros(batch, nmax, self.num_channels, device=self.device, dtype=torch.float32)
-        o = 0
-        for i in range(batch):
-            out[i, :durs[i]] = out_packed[o:o + durs[i]]
-            o += durs[i]
+        if all(n == nmax for n in lay):
+            out = out_packed.view(batch, nmax, self.num_channels)
+        else:
+            out = torch.zeros(batch, nmax, self.num_channels, device=self.device, dtype=torch.float32)
+            o = 0
+            for i in range(batch):
+                out[i, :lay[i]] = out_packed[o:o + lay[i]]
+                o += lay[i]
         if no_ref_audio:   # cfm.py:157-158: the final overwrite then copies zeros
             out = torch.where(cond_mask[..., None].to(self.device), torch.zeros_like(out), out)
         if vocoder is not None:
