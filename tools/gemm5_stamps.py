@@ -17,3 +17,9 @@ for N, K, act, out16, res in ((1024, 1024, "none", False, True), (1024, 64, "non
     w = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
     r = torch.randn(M, N, generator=g).cuda() if res else None
     ops.gemm(a, w, torch.zeros(N), prec=3, act=act, res=r, mul=torch.ones(N) if res else None, out16=out16, w_copies=32)
+
+D = 1024
+g = torch.Generator().manual_seed(2)
+a = torch.randn(M, D, generator=g).cuda()
+w = (torch.randn(3 * D, D, generator=g) / 32).cuda()
+ops.qkv(a, w, torch.zeros(3 * D), [i % 1404 for i in range(M)], prec=3)

@@ -9,12 +9,17 @@
 #pragma once
 #include "attn_common.h"
 
-static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn3_fwd_kernel(const AttnArgs p) {
+// NW = waves per workgroup = 32-query slices per query tile (4, 6 or 8).  The launcher picks NW so that the grid fills the 256 CUs in
+// whole rounds: at the C2 shape (2 sequences x 16 heads x 1404 queries) 256-query tiles give 192 workgroups -- 64 CUs idle for the whole
+// launch -- while 192-query tiles (NW = 6) give exactly 256 workgroups with 3/4 of the work each.
+template <int NW>
+static __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn3_fwd_kernel(const AttnArgs p) {
     constexpr int NST = 5, STAGE = 16384;
+    constexpr int P_HI = (16 + NW - 1) / NW, P_LO = 16 / NW;   // 1 KiB pieces of a KV tile per wave (pieces w, w + NW, ...)
     __shared__ __attribute__((aligned(16))) char smem[NST * STAGE];
     const int seq = blockIdx.z, head = blockIdx.y;
     const int len = p.seq_len[seq], kvlen = p.seq_kvlen[seq], row0 = p.seq_row0[seq];
-    const int q0 = blockIdx.x * 256;
+    const int q0 = blockIdx.x * (32 * NW);
     if (q0 >= len) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -34,19 +39,36 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2
     // ordinary VGPR load, and it would put that wait inside the KV loop, draining the ring every tile.
     asm volatile("" ::"v"(qf[0]), "v"(qf[1]), "v"(qf[2]), "v"(qf[3]) : "memory");
 
-    // LDS-DMA: a KV tile is 8 K pieces + 8 V^T pieces of 1 KiB (8 rows x 128 B); wave w moves K piece w and V piece w.
-    // Physical 16-B slot (lane & 7) of row r holds logical chunk (lane & 7) ^ ((r >> 1) & 7)  (same swizzle as attn.h).
-    const int prow = wave * 8 + (lane >> 3);
-    const int chunk = (lane & 7) ^ ((prow >> 1) & 7);
-    const char* ksrc = reinterpret_cast<const char*>(p.qk + (size_t)(row0 + prow) * (2 * D) + D + head * 64 + chunk * 8);
-    const char* vsrc = reinterpret_cast<const char*>(p.vt + (size_t)(head * 64 + prow) * p.ldvt + row0 + chunk * 8);
-    const size_t kstep = (size_t)64 * (2 * D) * 2, vstep = 64 * 2;   // bytes per KV tile
+    // LDS-DMA: a KV tile is 8 K pieces + 8 V^T pieces of 1 KiB (8 rows x 128 B); wave w moves pieces w, w + NW, ... (0-7 = K, 8-15 = V^T).
+    // Physical 16-B slot (lane & 7) of row r holds logical chunk (lane & 7) ^ ((r >> 1) & 7)  (same swizzle as the fragment reads).
+    const int mine = (16 - wave + NW - 1) / NW;
+    const char* src[P_HI];
+    size_t step[P_HI];
+#pragma unroll
+    for (int j = 0; j < P_HI; j++) {
+        const int pc = wave + NW * j;
+        const int prow = (pc & 7) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((prow >> 1) & 7);
+        const bool isK = pc < 8;
+        src[j] = isK ? reinterpret_cast<const char*>(p.qk + (size_t)(row0 + prow) * (2 * D) + D + head * 64 + chunk * 8)
+                     : reinterpret_cast<const char*>(p.vt + (size_t)(head * 64 + prow) * p.ldvt + row0 + chunk * 8);
+        step[j] = isK ? (size_t)64 * (2 * D) * 2 : (size_t)64 * 2;   // bytes per KV tile
+    }
     auto issue_tile = [&](int kt) {
         char* dst = smem + (kt % NST) * STAGE + wave * 1024;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ksrc + kt * kstep),
-                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vsrc + kt * vstep),
-                                         (__attribute__((address_space(3))) void*)(dst + 8192), 16, 0, 0);
+#pragma unroll
+        for (int j = 0; j < P_HI; j++)
+            if (j < P_LO || wave + NW * j < 16)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + kt * step[j]),
+                                                 (__attribute__((address_space(3))) void*)(dst + j * NW * 1024), 16, 0, 0);
+    };
+    // this wave's pieces of a tile have landed when at most `newer` younger tiles of its own are in flight
+    auto wait_landed = [&](int newer) {
+        if (mine == P_HI) {
+            if (newer >= 3) attn_wait_vmcnt<3 * P_HI>(); else if (newer == 2) attn_wait_vmcnt<2 * P_HI>(); else if (newer == 1) attn_wait_vmcnt<P_HI>(); else attn_wait_vmcnt<0>();
+        } else {
+            if (newer >= 3) attn_wait_vmcnt<3 * P_LO>(); else if (newer == 2) attn_wait_vmcnt<2 * P_LO>(); else if (newer == 1) attn_wait_vmcnt<P_LO>(); else attn_wait_vmcnt<0>();
+        }
     };
 
     f32x16 oacc[2];
@@ -142,10 +164,7 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2
     };
     // ring step kt: tile kt + 1 landed (its K feeds the next score tile); every wave is past step kt - 1, so stage (kt - 1) % NST is free
     auto ring_step = [&](int kt) {
-        const int newer = min(2, nkt - 2 - kt);   // tiles kt + 2, kt + 3 may stay in flight
-        if (newer >= 2) attn_wait_vmcnt<4>();
-        else if (newer == 1) attn_wait_vmcnt<2>();
-        else attn_wait_vmcnt<0>();
+        wait_landed(min(2, nkt - 2 - kt));   // tiles kt + 2, kt + 3 may stay in flight
         __builtin_amdgcn_s_barrier();
         if (kt + NST - 1 < nkt) issue_tile(kt + NST - 1);
     };
@@ -163,7 +182,7 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2
     }
     f32x16 sa[2], sb[2];   // the two score tiles swap roles every step (loop unrolled by two: no register copies)
     // tile 0 must have landed before the first score tile: tiles 1..3 may stay in flight
-    if (nkt >= 4) attn_wait_vmcnt<6>(); else if (nkt == 3) attn_wait_vmcnt<4>(); else if (nkt == 2) attn_wait_vmcnt<2>(); else attn_wait_vmcnt<0>();
+    wait_landed(min(3, nkt - 1));
     __builtin_amdgcn_s_barrier();
     qk_tile(sa, 0);
     A3_STAMP(-1);

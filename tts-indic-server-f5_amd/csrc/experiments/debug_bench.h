@@ -112,7 +112,7 @@ extern "C" int f5hip_debug_attn_stamps(int32_t n, int32_t heads, int32_t iters, 
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int it = -2; it < iters; it++) {
         if (it == 0) hipEventRecord(e0, 0);
-        hipLaunchKernelGGL(attn3_fwd_kernel, dim3((n + 255) / 256, heads, n_seq), dim3(512), 0, 0, at);
+        hipLaunchKernelGGL(attn3_fwd_kernel<8>, dim3((n + 255) / 256, heads, n_seq), dim3(512), 0, 0, at);
     }
     hipEventRecord(e1, 0); hipEventSynchronize(e1);
     float ms = 0; hipEventElapsedTime(&ms, e0, e1);

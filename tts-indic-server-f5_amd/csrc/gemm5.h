@@ -1,5 +1,5 @@
 // gemm5: exact-fit, full-line MFMA GEMM for gfx950 -- the production kernel of the transformer-block GEMMs (one 16-bit plane).
-//   C[M,N] = A[M,K] * W[N,K]^T, fp16 or bf16 operands, fp32 accumulate, epilogues of gemm_epilogue.h.
+//   C[M,N] = A[M,K] * W[N,K]^T, fp16 or bf16 operands, fp32 accumulate, fused epilogues (GemmArgs of gemm_epilogue.h).
 //
 // Why (profiles/r02_fillrate_microbench.txt, tools/fillrate.hip): at one utterance per GPU the k-loop of these GEMMs is bound by the
 // operand fill L2 -> LDS, not by the matrix pipe.  The round-1 kernel (gemm3.h: 128 x 128 tiles, 32-deep k-steps = 64-byte row
@@ -18,9 +18,16 @@
 // 2 x 2 for 128 columns, 1 x 4 for 192.  Why the roles are separate waves, and what the consumer loop must look like, is measured
 // (profiles/r02_gemm5_ablation.txt): pure loader 0.35 us per k-step, MFMAs alone 0.34, and an 8-wave kernel whose waves all did both
 // took 0.59 -- the sum: a wave blocked in VMEM issue cannot issue MFMAs, and its SIMD partner is blocked at the same moment.
-// Epilogue: accumulators -> one fp32 slab of the whole tile in LDS (it aliases the dead ring) -> all eight waves run the shared row
-// phase on 8-row x 64-column items (16-byte row-contiguous residual loads / stores).  V blocks of the QKV projection are stored
-// transposed straight from the accumulators (the 16 x 16 C layout holds 4 consecutive tokens per lane).
+//
+// Epilogue: accumulators -> one fp32 slab of the whole tile in LDS (it aliases the dead ring) -> all eight waves run a row phase with
+// 16-byte row-contiguous residual loads / stores.  The in-kernel time lines (profiles/r02_gemm5_timeline_stamps*.txt) showed the
+// epilogue's time following the amount of straight-line CODE it executes, not its bytes (V tiles 2.9 us, Q / K tiles 6.2, rotary tiles
+// 8.9; 3.4 us for out and FF1 alike): every launch walks it once, instruction-cache cold.  Hence
+//   * the W fragment is the MFMA's A operand (SWAP): a lane then holds 4 consecutive FEATURES of one token, and a 16 x 16 block goes to
+//     the row-major slab with ONE ds_write_b128 instead of four ds_write_b32 (all-V tiles of the QKV projection keep the other order:
+//     4 consecutive tokens per lane = one ds_write_b128 into the transposed slab their [feature][token] output wants);
+//   * the row phase is a rolled, one-deep software-pipelined loop over groups of 4 rows (residual of the next group in flight while the
+//     current one is finished), the (activation x residual x output x guard) variant chosen once per kernel outside it.
 #pragma once
 #include <stdlib.h>
 
@@ -39,9 +46,11 @@ struct Gemm5Cfg {
     static constexpr int BM = RB * 16, BN = CB * 16;
     static constexpr int PIECES = (BM + BN) / 8;          // 1 KiB LDS-DMA pieces (8 rows x 128 B) per k-step
     static constexpr int STAGE = PIECES * 1024;
-    static constexpr int SLD = BN + 4;                    // fp32 slab row stride: +4 floats keeps the transposing ds_write_b32 at 2-way (free)
-    static constexpr int RING = NST * STAGE, SLAB = BM * SLD * 4;
-    static constexpr int LDS = RING > SLAB ? RING : SLAB;
+    static constexpr int SLD = BN + 4;                    // row-major slab [token][feature]: +4 floats spreads the ds_write_b128 of 8 lanes over all banks
+    static constexpr int SLDT = BM + 4;                   // transposed slab [feature][token] (V blocks of the QKV projection)
+    static constexpr int NPAN = CB / 4;                   // 64-column panels
+    static constexpr int RING = NST * STAGE, SLAB = BM * SLD * 4, SLAB_T = BN * SLDT * 4;
+    static constexpr int LDS = RING > SLAB ? (RING > SLAB_T ? RING : SLAB_T) : (SLAB > SLAB_T ? SLAB : SLAB_T);
     static_assert(LDS <= 160 * 1024, "tile does not fit the LDS");
     static_assert(CB % 4 == 0, "column blocks must split over 64-column panels");
 };
@@ -52,12 +61,310 @@ F5_DEVICE int gemm5_tile_of_block(int b, int n_tiles) {
     return (b & 7) * (n_tiles >> 3) + (b >> 3);
 }
 
-// ABL (diagnostics, -DF5HIP_GEMM5_ABL builds + F5HIP_GEMM5_ABL=<n> at run time; results are garbage): 1 = no MFMAs, 2 = no fragment reads and
-// no MFMAs, 3 = no LDS-DMA inside the loop, 4 = MFMAs only (no DMA, no fragment reads)
+// ---------------------------------------------------------------------------------------------------------------------------------
+// consumer k-loop.  Software pipeline over half k-steps (32 deep) with ONE set of token-side fragments: right behind the MCB MFMAs that
+// consumed row block i, its registers are re-loaded with block i of the next half step ("rolling"), so every ds_read_b128 is in flight
+// for a whole half step (MRB x MCB MFMAs) and the 176 x 192 tile of QKV (132 accumulator registers) still fits 256 VGPRs; the W-side
+// fragments (MCB <= 6) are double-buffered.  No per-block guard: a wave with fewer than MRB row blocks (RB not a multiple of WR) also
+// multiplies the block after its last one -- in-bounds LDS rows of the same tile, a result that is never stored -- so the loop is
+// branch-free, and with no LDS-DMA in this branch hipcc's lgkmcnt bookkeeping stays exact (counted waits, no lgkmcnt(0): with the
+// builtin global_load_lds in the same loop every wait degraded to lgkmcnt(0), "pending flat").
+// SWAP: the W fragment is the MFMA's A operand: acc[i][j][e] = C[token (rb0 + i) 16 + (lane & 15)][feature (cb0 + j) 16 + 4 (lane >> 4) + e];
+// !SWAP: acc[i][j][e] = C[token (rb0 + i) 16 + 4 (lane >> 4) + e][feature (cb0 + j) 16 + (lane & 15)].
+// ABL (diagnostics, -DF5HIP_GEMM5_ABL builds + F5HIP_GEMM5_ABL=<n> at run time; results are garbage): 1 = no MFMAs, 2 = no fragment
+// reads and no MFMAs, 3 = no LDS-DMA inside the loop, 4 = MFMAs only (no DMA, no fragment reads), 5 = s_memrealtime stamps.
+template <bool F16, int BM, int STAGE, int NST, int MRB, int MCB, bool SWAP, int ABL>
+F5_DEVICE void g5_consume(const char* smem, int nk, int rb0, int cb0, int lane, f32x4 (&acc)[MRB][MCB]) {
+    // fragment byte offsets inside a stage: row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); block bases are multiples of 16 rows, so the
+    // swizzle term depends on the lane only; k-half 1 is k-half 0 with chunk bit 2 flipped (^ 64 bytes)
+    const int fr = lane & 15, fq = lane >> 4;
+    const int off0 = fr * 128 + ((fq ^ (fr >> 1)) << 4);
+#pragma unroll
+    for (int i = 0; i < MRB; i++)
+#pragma unroll
+        for (int j = 0; j < MCB; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bf16x8 fa[MRB], fb[2][MCB];
+    auto a_ptr = [&](int kt, int ks) { return smem + (kt % NST) * STAGE + rb0 * 2048 + (ks ? (off0 ^ 64) : off0); };
+    auto b_ptr = [&](int kt, int ks) { return smem + (kt % NST) * STAGE + (BM + cb0 * 16) * 128 + (ks ? (off0 ^ 64) : off0); };
+    auto read_b = [&](int buf, const char* sb) {
+        if ((ABL == 2 || ABL == 4) && sb != b_ptr(0, 0)) return;
+#pragma unroll
+        for (int j = 0; j < MCB; j++) fb[buf][j] = *reinterpret_cast<const bf16x8*>(sb + j * 2048);
+    };
+    // one half step: MFMAs of (fa, fb[buf]) with the rolling reload of fa from `sa_next` (RELOAD = false: last half step)
+    auto half_step = [&](auto reload, int buf, const char* sa_next) {
+        constexpr bool RELOAD = decltype(reload)::value;
+#pragma unroll
+        for (int i = 0; i < MRB; i++) {
+            if (ABL == 1 || ABL == 2) {
+                asm volatile("" :: "v"(fa[i]), "v"(fb[buf][0]), "v"(fb[buf][MCB - 1]));
+            } else {
+#pragma unroll
+                for (int j = 0; j < MCB; j++)
+                    acc[i][j] = SWAP ? mfma_16x16x32<F16>(fb[buf][j], fa[i], acc[i][j]) : mfma_16x16x32<F16>(fa[i], fb[buf][j], acc[i][j]);
+            }
+            if (RELOAD && ABL != 2 && ABL != 4) fa[i] = *reinterpret_cast<const bf16x8*>(sa_next + i * 2048);
+        }
+    };
+    constexpr std::integral_constant<bool, true> ROLL{};
+    constexpr std::integral_constant<bool, false> LAST{};
+    __builtin_amdgcn_s_barrier();                              // B_0: k-step 0 landed
+    asm volatile("" ::: "memory");
+    read_b(0, b_ptr(0, 0));
+#pragma unroll
+    for (int i = 0; i < MRB; i++) fa[i] = *reinterpret_cast<const bf16x8*>(a_ptr(0, 0) + i * 2048);
+    for (int kt = 0; kt + 1 < nk; kt++) {
+        read_b(1, b_ptr(kt, 1));
+        half_step(ROLL, 0, a_ptr(kt, 1));
+        // every read of stage kt % NST has been issued; the builtin (not an asm statement) lets hipcc know they have all returned
+        __builtin_amdgcn_s_waitcnt(0xC07F);                    // lgkmcnt(0)
+        __builtin_amdgcn_s_barrier();                          // B_{kt+1}
+        asm volatile("" ::: "memory");
+        read_b(0, b_ptr(kt + 1, 0));
+        half_step(ROLL, 1, a_ptr(kt + 1, 0));
+    }
+    read_b(1, b_ptr(nk - 1, 1));
+    half_step(ROLL, 0, a_ptr(nk - 1, 1));
+    half_step(LAST, 1, nullptr);
+}
+
+// consumers: accumulators -> slab.  ROWMAJOR: slab[token][feature] (stride SLD); else slab[feature][token] (stride SLDT, + bias: V blocks).
+// One ds_write_b128 per block when the lane's 4 values are contiguous in the target (SWAP & ROWMAJOR, or !SWAP & transposed).
+template <int RB, int CB, int NST, int WR, int MRB, int MCB, bool SWAP, bool ROWMAJOR>
+F5_DEVICE void g5_write_slab(f32x4 (&acc)[MRB][MCB], float* slab, int rb0, int nrb, int cb0, int lane, const float* bias_tile, int j_first = 0) {
+    using C = Gemm5Cfg<RB, CB, NST>;
+    const int fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+    for (int j = 0; j < MCB; j++) {
+        if (j < j_first) continue;                             // (straddling K | V tile: only the V blocks go to the transposed slab)
+        f32x4 bj = {0.f, 0.f, 0.f, 0.f};
+        if (!ROWMAJOR) {
+            if (SWAP) bj = *reinterpret_cast<const f32x4*>(bias_tile + (cb0 + j) * 16 + fq * 4);
+            else { const float b1 = bias_tile[(cb0 + j) * 16 + fr]; bj = (f32x4){b1, b1, b1, b1}; }
+        }
+#pragma unroll
+        for (int i = 0; i < MRB; i++) {
+            if (RB % WR == 0 || i < nrb) {
+                if (SWAP && ROWMAJOR) {
+                    *reinterpret_cast<f32x4*>(slab + ((rb0 + i) * 16 + fr) * C::SLD + (cb0 + j) * 16 + fq * 4) = acc[i][j];
+                } else if (!SWAP && !ROWMAJOR) {
+                    *reinterpret_cast<f32x4*>(slab + ((cb0 + j) * 16 + fr) * C::SLDT + (rb0 + i) * 16 + fq * 4) = acc[i][j] + bj;
+                } else if (SWAP) {                             // transposed from the SWAP layout: four scalars (V blocks of a straddling tile)
+                    float* d = slab + ((cb0 + j) * 16 + fq * 4) * C::SLDT + (rb0 + i) * 16 + fr;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) d[e * C::SLDT] = acc[i][j][e] + bj[e];
+                } else {                                       // row-major from the !SWAP layout (not used on the path)
+                    float* d = slab + ((rb0 + i) * 16 + fq * 4) * C::SLD + (cb0 + j) * 16 + fr;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) d[e * C::SLD] = acc[i][j][e];
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// generic row phase: v = act(acc + bias); rows with row_keep == 0 -> 0; v = v * mul + res; fp32 and / or 16-bit outputs.
+// Work unit = one group of 4 rows x the tile's NPAN panels of 64 columns (lane -> row lane >> 4, columns 4 (lane & 15) .. + 3 of each
+// panel); groups are dealt round-robin over the 8 waves; the loop is rolled, the next group's residual is loaded before the current
+// group is finished.
+template <int ACT, bool RES, bool OUTF, int OUTS, bool GUARD, int RB, int CB, int NST, typename WriteSlab>
+F5_DEVICE void g5_generic_tail(const GemmArgs& p, const float* slab, int m0, int n0, int wave, int lane, WriteSlab write_slab) {
+    using C = Gemm5Cfg<RB, CB, NST>;
+    constexpr int NPAN = C::NPAN, NG = RB * 4;                 // row groups of the tile
+    const int r_in = lane >> 4, c4 = (lane & 15) * 4;
+    f32x4 bv[NPAN], mv[NPAN];
+    bool nok[NPAN];
+#pragma unroll
+    for (int pn = 0; pn < NPAN; pn++) {
+        const int n = n0 + pn * 64 + c4;
+        nok[pn] = GUARD ? n < p.N : true;
+        bv[pn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        mv[pn] = (f32x4){1.f, 1.f, 1.f, 1.f};
+        if (p.bias && nok[pn]) bv[pn] = *reinterpret_cast<const f32x4*>(p.bias + n);
+        if (p.mul && nok[pn]) mv[pn] = *reinterpret_cast<const f32x4*>(p.mul + n);
+    }
+    f32x4 rs[RES ? NPAN : 1], rn[RES ? NPAN : 1];
+    auto load_res = [&](int g, f32x4 (&dst)[RES ? NPAN : 1]) {
+        if (!RES) return;
+        const int row = m0 + g * 4 + r_in;
+#pragma unroll
+        for (int pn = 0; pn < NPAN; pn++) {
+            dst[pn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (g < NG && (!GUARD || (nok[pn] && row < p.M))) dst[pn] = *reinterpret_cast<const f32x4*>(p.res + (size_t)row * p.ldres + n0 + pn * 64 + c4);
+        }
+    };
+    load_res(wave, rs);                                            // in flight across the slab write and its barrier
+    write_slab();
+    __syncthreads();                                               // E2: the slab is complete
+#pragma unroll 1
+    for (int g = wave; g < NG; g += 8) {
+        load_res(g + 8, rn);
+        const int rl = g * 4 + r_in, row = m0 + rl;
+        int keep = 1;
+        if (GUARD && p.row_keep && row < p.M) keep = p.row_keep[row];
+#pragma unroll
+        for (int pn = 0; pn < NPAN; pn++) {
+            const int n = n0 + pn * 64 + c4;
+            f32x4 v = *reinterpret_cast<const f32x4*>(slab + rl * C::SLD + pn * 64 + c4) + bv[pn];
+            if (ACT != ACT_NONE) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) v[e] = apply_act(v[e], ACT);
+            }
+            if (GUARD && !keep) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+            v = v * mv[pn];
+            if (RES) v = v + rs[pn];
+            if (!GUARD || (nok[pn] && row < p.M)) {
+                if (OUTF) *reinterpret_cast<f32x4*>(p.out_f32 + (size_t)row * p.ldo + n) = v;
+                const float vv[4] = {v[0], v[1], v[2], v[3]};
+                if (OUTS == 2) {
+                    store_f16x4(p.out_hi + (size_t)row * p.ldob + n, vv);
+                } else if (OUTS == 1) {
+                    bf16x4 hi, lo;
+                    split_bf16x4(vv, hi, lo);
+                    *reinterpret_cast<bf16x4*>(p.out_hi + (size_t)row * p.ldob + n) = hi;
+                    if (p.out_lo) *reinterpret_cast<bf16x4*>(p.out_lo + (size_t)row * p.ldob + n) = lo;
+                }
+            }
+        }
+        if (RES) {
+#pragma unroll
+            for (int pn = 0; pn < NPAN; pn++) rs[pn] = rn[pn];
+        }
+    }
+}
+
+template <int ACT, bool GUARD, int RB, int CB, int NST, typename WriteSlab>
+F5_DEVICE void g5_generic_variants(const GemmArgs& p, const float* slab, int m0, int n0, int wave, int lane, WriteSlab ws) {
+    const bool res = p.res != nullptr, outf = p.out_f32 != nullptr, outs = p.out_hi != nullptr;
+    // the (residual, fp32 out, 16-bit out) combinations in use on the path: same table as epi_generic_rows_g (gemm_epilogue.h)
+    if (ACT == ACT_NONE) {
+        if (res) {
+            if (outf && outs) g5_generic_tail<ACT, true, true, 1, GUARD, RB, CB, NST>(p, slab, m0, n0, wave, lane, ws);
+            else if (outf) g5_generic_tail<ACT, true, true, 0, GUARD, RB, CB, NST>(p, slab, m0, n0, wave, lane, ws);
+            else g5_generic_tail<ACT, true, false, 1, GUARD, RB, CB, NST>(p, slab, m0, n0, wave, lane, ws);
+        } else {
+            if (outf && outs) g5_generic_tail<ACT, false, true, 1, GUARD, RB, CB, NST>(p, slab, m0, n0, wave, lane, ws);
+            else if (outf) g5_generic_tail<ACT, false, true, 0, GUARD, RB, CB, NST>(p, slab, m0, n0, wave, lane, ws);
+            else if (p.f16_out) g5_generic_tail<ACT, false, false, 2, GUARD, RB, CB, NST>(p, slab, m0, n0, wave, lane, ws);
+            else g5_generic_tail<ACT, false, false, 1, GUARD, RB, CB, NST>(p, slab, m0, n0, wave, lane, ws);
+        }
+    } else {
+        if (res) g5_generic_tail<ACT, true, true, 0, GUARD, RB, CB, NST>(p, slab, m0, n0, wave, lane, ws);
+        else if (outs && !outf && p.f16_out) g5_generic_tail<ACT, false, false, 2, GUARD, RB, CB, NST>(p, slab, m0, n0, wave, lane, ws);
+        else if (outs && !outf) g5_generic_tail<ACT, false, false, 1, GUARD, RB, CB, NST>(p, slab, m0, n0, wave, lane, ws);
+        else if (outf && !outs) g5_generic_tail<ACT, false, true, 0, GUARD, RB, CB, NST>(p, slab, m0, n0, wave, lane, ws);
+        else g5_generic_tail<ACT, false, true, 1, GUARD, RB, CB, NST>(p, slab, m0, n0, wave, lane, ws);
+    }
+}
+
+template <int RB, int CB, int NST, typename WriteSlab>
+F5_DEVICE void g5_generic_epilogue(const GemmArgs& p, const float* slab, int m0, int n0, int wave, int lane, WriteSlab ws) {
+    // workgroup-uniform: interior tile without per-row special cases
+    const bool interior = m0 + RB * 16 <= p.M && n0 + CB * 16 <= p.N && !p.row_keep;
+#define G5_ACT(A)                                                                                 \
+    if (interior) g5_generic_variants<A, false, RB, CB, NST>(p, slab, m0, n0, wave, lane, ws);   \
+    else g5_generic_variants<A, true, RB, CB, NST>(p, slab, m0, n0, wave, lane, ws);
+    switch (p.act) {
+        case ACT_GELU_TANH: G5_ACT(ACT_GELU_TANH) break;
+        case ACT_GELU_ERF: G5_ACT(ACT_GELU_ERF) break;
+        case ACT_MISH: G5_ACT(ACT_MISH) break;
+        case ACT_SILU: G5_ACT(ACT_SILU) break;
+        default: G5_ACT(ACT_NONE) break;
+    }
+#undef G5_ACT
+}
+
+// Q / K rows of the fused QKV projection: bias, rotary embedding on head 0 (x-transformers interleaved pairs, applied before the head
+// split: F/model/modules.py:414-419), q / 8 (softmax scale, exact in bf16), bf16 row-major [M][2 D].  A 192-column tile can straddle
+// the Q | K or the K | V boundary: both are multiples of 64, so every 64-column panel is of one kind.
+template <int RB, int CB, int NST>
+F5_DEVICE void g5_qk_rows(const GemmArgs& p, const float* slab, int m0, int n0, int wave, int lane) {
+    using C = Gemm5Cfg<RB, CB, NST>;
+    constexpr int NPAN = C::NPAN, NG = RB * 4, NT = (NG + 7) / 8;
+    const int D = p.D, r_in = lane >> 4, c4 = (lane & 15) * 4;
+    f32x4 bv[NPAN];
+#pragma unroll
+    for (int pn = 0; pn < NPAN; pn++) bv[pn] = *reinterpret_cast<const f32x4*>(p.bias + n0 + pn * 64 + c4);
+    // head 0 of q = columns [0, 64), of k = [D, D + 64): at most one panel of a tile (workgroup-uniform)
+    int rot_pn = -1;
+#pragma unroll
+    for (int pn = 0; pn < NPAN; pn++) {
+        const int n_base = n0 + pn * 64;
+        if (n_base == 0 || n_base == D) rot_pn = pn;
+    }
+    // rotary factors of this wave's rows, all fetched up front (two dependent global loads per row group: inside the rolled loop they
+    // were ~1 us per group, and the 32 rotary tiles of the C2 launch finished 3 us behind the other 224)
+    float2 cs[NT], sn[NT];
+    if (rot_pn >= 0) {
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            const int row = m0 + (wave + 8 * t) * 4 + r_in;
+            const int pos = (wave + 8 * t < NG && row < p.M) ? p.row_pos[row] : 0;
+            cs[t] = *reinterpret_cast<const float2*>(p.rope_cos + pos * 32 + (c4 >> 1));
+            sn[t] = *reinterpret_cast<const float2*>(p.rope_sin + pos * 32 + (c4 >> 1));
+        }
+    }
+    auto finish = [&](int g, bool rot, float2 c, float2 s2) {
+        const int rl = g * 4 + r_in, row = m0 + rl;
+        const bool rok = row < p.M;
+#pragma unroll
+        for (int pn = 0; pn < NPAN; pn++) {
+            const int n_base = n0 + pn * 64;
+            if (n_base < 2 * D) {                                  // (wave-uniform)
+                const int which = n_base / D, nd = n_base - which * D + c4;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(slab + rl * C::SLD + pn * 64 + c4) + bv[pn];
+                const float qs = which == 0 ? 0.125f : 1.0f;
+                bf16x4 o;
+                if (rot && pn == rot_pn) {
+                    // explicit product + fma: left to the compiler, the contraction of a*c - b*s differed between instantiations of the
+                    // round-1 epilogue -- a 1-ulp bf16 flip in a few q values that the 22-layer sampler amplifies to 5e-4
+                    o[0] = (__bf16)(__builtin_fmaf(v[0], c.x, -__fmul_rn(v[1], s2.x)) * qs);
+                    o[1] = (__bf16)(__builtin_fmaf(v[1], c.x, __fmul_rn(v[0], s2.x)) * qs);
+                    o[2] = (__bf16)(__builtin_fmaf(v[2], c.y, -__fmul_rn(v[3], s2.y)) * qs);
+                    o[3] = (__bf16)(__builtin_fmaf(v[3], c.y, __fmul_rn(v[2], s2.y)) * qs);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) o[e] = (__bf16)(v[e] * qs);
+                }
+                if (rok) *reinterpret_cast<bf16x4*>(p.qk + (size_t)row * (2 * D) + which * D + nd) = o;
+            }
+        }
+    };
+    if (rot_pn >= 0) {
+#pragma unroll
+        for (int t = 0; t < NT; t++)
+            if (wave + 8 * t < NG) finish(wave + 8 * t, true, cs[t], sn[t]);
+    } else {
+#pragma unroll 1
+        for (int g = wave; g < NG; g += 8) finish(g, false, make_float2(1.f, 1.f), make_float2(0.f, 0.f));
+    }
+}
+
+// V rows: slab[feature][token] (bias added by the writer) -> [D][ldvt] bf16: lane-linear (feature, 4 tokens) pairs, 8-byte stores,
+// 2 RB x 16-byte runs of tokens per feature row
+template <int RB, int CB, int NST>
+F5_DEVICE void g5_v_rows(const GemmArgs& p, const float* slab, int m0, int n0, int f_lo, int wave, int lane) {
+    using C = Gemm5Cfg<RB, CB, NST>;
+    constexpr int T4 = RB * 4;                                     // groups of 4 tokens per feature row
+    const int n_items = (CB * 16 - f_lo) * T4;
+#pragma unroll 2
+    for (int idx = wave * 64 + lane; idx < n_items; idx += 512) {
+        const int f = f_lo + idx / T4, t4 = idx % T4;
+        const int tok = m0 + t4 * 4;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(slab + f * C::SLDT + t4 * 4);
+        bf16x4 pk;
+#pragma unroll
+        for (int e = 0; e < 4; e++) pk[e] = (__bf16)v[e];
+        if (tok < p.M) *reinterpret_cast<bf16x4*>(p.vt + (size_t)(n0 + f - 2 * p.D) * p.ldvt + tok) = pk;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
 template <bool F16, int EPI, int RB, int CB, int WR, int NST, int ABL = 0>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm5_kernel(const GemmArgs p, const int tiles_n, const int n_rows_w) {
     using C = Gemm5Cfg<RB, CB, NST>;
-    constexpr int BM = C::BM, BN = C::BN, PIECES = C::PIECES, STAGE = C::STAGE, SLD = C::SLD;
+    constexpr int BM = C::BM, BN = C::BN, PIECES = C::PIECES, STAGE = C::STAGE;
     constexpr int WC = 4 / WR;                                 // the 4 consumer waves tile the block grid WR (rows) x WC (columns)
     constexpr int MRB = (RB + WR - 1) / WR, MCB = CB / WC;
     static_assert(CB % WC == 0 && NST >= 3 && NST <= 4, "bad tile configuration");
@@ -77,7 +384,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int wr = cw / WC, wc = cw % WC;
     const int rb0 = (wr * RB) / WR, nrb = ((wr + 1) * RB) / WR - rb0;   // wave-uniform
     const int cb0 = wc * MCB;
-    const int fr = lane & 15, fq = lane >> 4;
+    // all-V tiles of the QKV projection keep the token on the accumulator registers (their output is [feature][token])
+    const bool swap = !(EPI == EPI_QKV && n0 >= 2 * p.D);
     f32x4 acc[MRB][MCB];
 
     // Ring protocol.  All NST stages are filled up front.  Barrier B_{kt+1} sits between the two 32-deep halves of k-step kt: behind it
@@ -85,8 +393,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // consumer waited lgkmcnt(0)), so the loaders issue k-step kt + NST into that stage at once: one stage being consumed, NST - 1 in flight.
     if (wave >= 4) {
         // ------------------------------------------------------------------ loader waves: they sit in VMEM issue for the whole k-loop
-        // (the CU's address path takes ~26 cycles per 1 KiB piece: profiles/r02_gemm5_ablation.txt), which is why they are not the waves
-        // that issue MFMAs: with all eight waves doing both, loader time and MFMA time added up instead of overlapping.
+        // (the CU's address path takes ~26 cycles per 1 KiB piece)
         const int pw = wave - 4;
         const int mine = (PIECES - pw + 3) >> 2;               // pieces pw, pw + 4, ... of every k-step (1 KiB = 8 rows x 128 B each)
         const char* gsrc[P_HI];
@@ -129,120 +436,39 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             __builtin_amdgcn_s_barrier();                      // B_{kt+1}
             if (kt + NST < nk) issue_tile(kt + NST);
         }
+    } else if (swap) {
+        g5_consume<F16, BM, STAGE, NST, MRB, MCB, true, ABL>(smem, nk, rb0, cb0, lane, acc);
     } else {
-        // ------------------------------------------------------------------ consumer waves, one per SIMD: LDS fragment reads + MFMAs only
-        // Fragment byte offsets inside a stage: row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); block bases are multiples of 16 rows, so the
-        // swizzle term depends on the lane only; k-half 1 is k-half 0 with chunk bit 2 flipped (^ 64 bytes).
-        const int off0 = fr * 128 + ((fq ^ (fr >> 1)) << 4);
-#pragma unroll
-        for (int i = 0; i < MRB; i++)
-#pragma unroll
-            for (int j = 0; j < MCB; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        // Software pipeline over half k-steps (32 deep) with ONE set of A fragments: right behind the MCB MFMAs that consumed row block
-        // i, its registers are re-loaded with block i of the next half step ("rolling"), so every ds_read_b128 is in flight for a whole
-        // half step (MRB x MCB MFMAs) and the 176 x 192 tile of QKV (132 accumulator registers) still fits 256 VGPRs; the B fragments
-        // (MCB <= 6) are double-buffered.  No per-block guard: a wave with fewer than MRB row blocks (RB not a multiple of WR) also
-        // multiplies the block after its last one -- in-bounds LDS rows of the same tile, a result that is never stored -- so the loop is
-        // branch-free, and with no LDS-DMA in this branch hipcc's lgkmcnt bookkeeping stays exact (counted waits, no lgkmcnt(0)).
-        bf16x8 fa[MRB], fb[2][MCB];
-        auto a_ptr = [&](int kt, int ks) { return smem + (kt % NST) * STAGE + rb0 * 2048 + (ks ? (off0 ^ 64) : off0); };
-        auto b_ptr = [&](int kt, int ks) { return smem + (kt % NST) * STAGE + (BM + cb0 * 16) * 128 + (ks ? (off0 ^ 64) : off0); };
-        auto read_b = [&](int buf, const char* sb) {
-            if ((ABL == 2 || ABL == 4) && sb != b_ptr(0, 0)) return;
-#pragma unroll
-            for (int j = 0; j < MCB; j++) fb[buf][j] = *reinterpret_cast<const bf16x8*>(sb + j * 2048);
-        };
-        // one half step: MFMAs of (fa, fb[buf]) with the rolling reload of fa from `sa_next` (RELOAD = false: last half step)
-        auto half_step = [&](auto reload, int buf, const char* sa_next) {
-            constexpr bool RELOAD = decltype(reload)::value;
-#pragma unroll
-            for (int i = 0; i < MRB; i++) {
-                if (ABL == 1 || ABL == 2) {
-                    asm volatile("" :: "v"(fa[i]), "v"(fb[buf][0]), "v"(fb[buf][MCB - 1]));
-                } else {
-#pragma unroll
-                    for (int j = 0; j < MCB; j++) acc[i][j] = mfma_16x16x32<F16>(fa[i], fb[buf][j], acc[i][j]);
-                }
-                if (RELOAD && ABL != 2 && ABL != 4) fa[i] = *reinterpret_cast<const bf16x8*>(sa_next + i * 2048);
-            }
-        };
-        constexpr std::integral_constant<bool, true> ROLL{};
-        constexpr std::integral_constant<bool, false> LAST{};
-        __builtin_amdgcn_s_barrier();                          // B_0: k-step 0 landed
-        asm volatile("" ::: "memory");
-        read_b(0, b_ptr(0, 0));
-#pragma unroll
-        for (int i = 0; i < MRB; i++) fa[i] = *reinterpret_cast<const bf16x8*>(a_ptr(0, 0) + i * 2048);
-        for (int kt = 0; kt + 1 < nk; kt++) {
-            read_b(1, b_ptr(kt, 1));
-            half_step(ROLL, 0, a_ptr(kt, 1));
-            // every read of stage kt % NST has been issued; the builtin (not an asm statement) lets hipcc know they have all returned
-            __builtin_amdgcn_s_waitcnt(0xC07F);                // lgkmcnt(0)
-            __builtin_amdgcn_s_barrier();                      // B_{kt+1}
-            asm volatile("" ::: "memory");
-            read_b(0, b_ptr(kt + 1, 0));
-            half_step(ROLL, 1, a_ptr(kt + 1, 0));
-        }
-        read_b(1, b_ptr(nk - 1, 1));
-        half_step(ROLL, 0, a_ptr(nk - 1, 1));
-        half_step(LAST, 1, nullptr);
+        g5_consume<F16, BM, STAGE, NST, MRB, MCB, false, ABL>(smem, nk, rb0, cb0, lane, acc);
     }
 
     G5_STAMP(2);
     __syncthreads();                                               // E1: the ring is dead
     G5_STAMP(3);
-    if (wave < 4) {
-        float* slab = reinterpret_cast<float*>(smem);
-#pragma unroll
-        for (int j = 0; j < MCB; j++) {
-            const int ncol = n0 + (cb0 + j) * 16 + fr;             // column in the padded weight layout
-            if (EPI == EPI_QKV && n0 + (cb0 + j) * 16 >= 2 * p.D) {
-                // V block (wave-uniform: 2 D is a multiple of 16): [feature][token] bf16, 4 consecutive tokens = 8 bytes per store
-                const float bv = p.bias[ncol];
-#pragma unroll
-                for (int i = 0; i < MRB; i++) {
-                    if (RB % WR == 0 || i < nrb) {
-                        const int mrow = m0 + (rb0 + i) * 16 + fq * 4;
-                        bf16x4 pk;
-#pragma unroll
-                        for (int e = 0; e < 4; e++) pk[e] = (__bf16)(acc[i][j][e] + bv);
-                        if (mrow < p.M) *reinterpret_cast<bf16x4*>(p.vt + (size_t)(ncol - 2 * p.D) * p.ldvt + mrow) = pk;
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < MRB; i++) {
-                    if (RB % WR == 0 || i < nrb) {
-                        float* d = slab + ((rb0 + i) * 16 + fq * 4) * SLD + (cb0 + j) * 16 + fr;
-#pragma unroll
-                        for (int e = 0; e < 4; e++) d[e * SLD] = acc[i][j][e];
-                    }
-                }
-            }
+    float* slab = reinterpret_cast<float*>(smem);
+    if constexpr (EPI == EPI_GENERIC) {
+        g5_generic_epilogue<RB, CB, NST>(p, slab, m0, n0, wave, lane, [&]() {
+            if (wave < 4) g5_write_slab<RB, CB, NST, WR, MRB, MCB, true, true>(acc, slab, rb0, nrb, cb0, lane, nullptr);
+        });
+    } else if (swap) {
+        // Q / K tile (possibly with V blocks behind the K | V boundary): row-major slab, rolled row phase; then the V blocks, if any
+        if (wave < 4) g5_write_slab<RB, CB, NST, WR, MRB, MCB, true, true>(acc, slab, rb0, nrb, cb0, lane, nullptr);
+        __syncthreads();                                           // E2
+        g5_qk_rows<RB, CB, NST>(p, slab, m0, n0, wave, lane);
+        const int f_lo = 2 * p.D - n0;                             // first V column of this tile (>= BN: none)
+        if (f_lo < BN) {                                           // (workgroup-uniform)
+            __syncthreads();                                       // the Q / K rows are done with the slab
+            // column blocks at or behind the boundary (a multiple of 16) go to the transposed slab
+            if (wave < 4) g5_write_slab<RB, CB, NST, WR, MRB, MCB, true, false>(acc, slab, rb0, nrb, cb0, lane, p.bias + n0, max(0, f_lo / 16 - cb0));
+            __syncthreads();
+            g5_v_rows<RB, CB, NST>(p, slab, m0, n0, f_lo, wave, lane);
         }
+    } else {
+        if (wave < 4) g5_write_slab<RB, CB, NST, WR, MRB, MCB, false, false>(acc, slab, rb0, nrb, cb0, lane, p.bias + n0);
+        __syncthreads();                                           // E2
+        g5_v_rows<RB, CB, NST>(p, slab, m0, n0, 0, wave, lane);
     }
-    __syncthreads();                                               // E2: the slab is complete
     G5_STAMP(4);
-
-    // ---------------------------------------------------------------------- row phase, all eight waves: items of 8 rows x 64 columns
-    constexpr int NPAN = CB / 4, ITEMS = NPAN * RB * 2;
-    const float* slab = reinterpret_cast<const float*>(smem);
-    for (int it = wave; it < ITEMS; it += 8) {
-        const int pan = it % NPAN, ch = it / NPAN;
-        const int m_base = m0 + ch * 8, n_base = n0 + pan * 64;
-        const float* stg = slab + ch * 8 * SLD + pan * 64;
-        if (EPI == EPI_GENERIC) {
-            switch (p.act) {
-                case ACT_GELU_TANH: epi_generic_rows<ACT_GELU_TANH, 64, 8, SLD>(p, stg, m_base, n_base, lane); break;
-                case ACT_GELU_ERF: epi_generic_rows<ACT_GELU_ERF, 64, 8, SLD>(p, stg, m_base, n_base, lane); break;
-                case ACT_MISH: epi_generic_rows<ACT_MISH, 64, 8, SLD>(p, stg, m_base, n_base, lane); break;
-                case ACT_SILU: epi_generic_rows<ACT_SILU, 64, 8, SLD>(p, stg, m_base, n_base, lane); break;
-                default: epi_generic_rows<ACT_NONE, 64, 8, SLD>(p, stg, m_base, n_base, lane); break;
-            }
-        } else if (n_base < 2 * p.D) {                             // (V panels were stored by the consumers)
-            epi_qk_rows<64, 8, SLD>(p, stg, m_base, n_base, lane);
-        }
-    }
     if constexpr (ABL == 5) {
         if (p.stamps && (tid == 0 || tid == 256)) {
             const unsigned long long t5 = __builtin_amdgcn_s_memrealtime();
@@ -270,8 +496,13 @@ static hipError_t launch_gemm5_t(const GemmArgs& a, int n_pad, hipStream_t st) {
 template <bool F16, int EPI>
 static hipError_t launch_gemm5(const GemmArgs& a, int rb, int cb, int n_pad, hipStream_t st) {
 #ifdef F5HIP_GEMM5_ABL
+    static const int abl = getenv("F5HIP_GEMM5_ABL") ? atoi(getenv("F5HIP_GEMM5_ABL")) : 0;
+    if (EPI == EPI_QKV && rb == 11 && cb == 12) {
+        if (abl == 5) return launch_gemm5_t<F16, EPI_QKV, 11, 12, 1, 3, 5>(a, n_pad, st);
+        if (abl == 2) return launch_gemm5_t<F16, EPI_QKV, 11, 12, 1, 3, 2>(a, n_pad, st);
+        if (abl == 4) return launch_gemm5_t<F16, EPI_QKV, 11, 12, 1, 3, 4>(a, n_pad, st);
+    }
     if (EPI == EPI_GENERIC && rb == 11 && (cb == 4 || cb == 8)) {
-        static const int abl = getenv("F5HIP_GEMM5_ABL") ? atoi(getenv("F5HIP_GEMM5_ABL")) : 0;
         if (cb == 4) {
             if (abl == 1) return launch_gemm5_t<F16, EPI_GENERIC, 11, 4, 4, 4, 1>(a, n_pad, st);
             if (abl == 2) return launch_gemm5_t<F16, EPI_GENERIC, 11, 4, 4, 4, 2>(a, n_pad, st);

@@ -19,6 +19,45 @@ static void op_pack_planes(const float* src, int R, int C, int R_pad, __bf16* hi
     hipLaunchKernelGGL(pack_weight_kernel, dim3(R_pad), dim3(256), 0, st, src, R, C, C, hi, f16 ? (__bf16*)nullptr : lo, C);
 }
 
+// diagnostics (-DF5HIP_GEMM5_ABL builds, F5HIP_GEMM5_ABL=5): s_memrealtime stamps (100 MHz) of wave 0 (consumer) and wave 4 (loader) of every workgroup
+template <typename Launch>
+static int gemm5_stamp_report(OpBufs& b, int M, int N, int K, hipStream_t st, Launch launch) {
+    const int maxg = 4096;
+    unsigned long long* d = b.get<unsigned long long>((size_t)maxg * 16);
+    if (!d) return 0;
+    (void)hipMemsetAsync(d, 0, sizeof(unsigned long long) * maxg * 16, st);
+    for (int rep = 0; rep < 3; rep++) CK(launch(d, rep));
+    (void)hipStreamSynchronize(st);
+    std::vector<unsigned long long> h((size_t)maxg * 16);
+    (void)hipMemcpy(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost);
+    unsigned long long tmin = ~0ull, tmax = 0;
+    int ng = 0;
+    for (int g2 = 0; g2 < maxg; g2++) if (h[(size_t)g2 * 16]) { ng = g2 + 1; tmin = std::min(tmin, h[(size_t)g2 * 16]); tmax = std::max(tmax, std::max(h[(size_t)g2 * 16 + 6], h[(size_t)g2 * 16 + 14])); }
+    const char* names[7] = {"start", "tile0 landed (loader)", "k-loop end", "E1 passed", "E2 passed (slab done)", "row phase issued", "stores drained"};
+    fprintf(stderr, "[gemm5 stamps] M %d N %d K %d: %d workgroups, first start -> last end %.2f us\n", M, N, K, ng, (tmax - tmin) * 0.01);
+    for (int w = 0; w < 2; w++)
+        for (int i = 0; i < 7; i++) {
+            std::vector<double> v;
+            for (int g2 = 0; g2 < ng; g2++) { const unsigned long long t = h[(size_t)g2 * 16 + w * 8 + i]; if (t) v.push_back((t - tmin) * 0.01); }
+            if (v.empty()) continue;
+            std::sort(v.begin(), v.end());
+            fprintf(stderr, "[gemm5 stamps]   wave %d  %-26s min %6.2f  median %6.2f  max %6.2f us after the first workgroup started\n", w * 4, names[i], v.front(), v[v.size() / 2], v.back());
+        }
+    // epilogue duration (E1 -> end of the row phase) by column slab of the tile (XCD-blocked order of gemm5_tile_of_block, 16 column slabs)
+    if (ng == 256) {
+        for (int tn = 0; tn < 16; tn++) {
+            std::vector<double> v;
+            for (int g2 = 0; g2 < ng; g2++) {
+                const int tile = (g2 & 7) * (ng >> 3) + (g2 >> 3);
+                if (tile % 16 == tn) v.push_back((h[(size_t)g2 * 16 + 5] - h[(size_t)g2 * 16 + 3]) * 0.01);
+            }
+            std::sort(v.begin(), v.end());
+            fprintf(stderr, "[gemm5 stamps]   column slab %2d: epilogue min %5.2f median %5.2f max %5.2f us\n", tn, v.front(), v[v.size() / 2], v.back());
+        }
+    }
+    return 0;
+}
+
 extern "C" int f5hip_op_gemm(int32_t M, int32_t N, int32_t K, const float* a_dev, const float* w_dev, const float* bias_dev, int32_t prec,
                              int32_t act, const float* mul_dev, const float* res_dev, const uint8_t* row_keep_host, float* out_dev,
                              uint16_t* out16_dev, int32_t w_copies, int32_t iters, double* avg_us, void* stream) {
@@ -63,35 +102,12 @@ extern "C" int f5hip_op_gemm(int32_t M, int32_t N, int32_t K, const float* a_dev
         GemmArgs g = args_for(Ws[0]);
         CK(run_gemm_n(prec, M_pad, g, Ws[0], EPI_GENERIC, false, 128, st));
     }
-    if (getenv("F5HIP_GEMM5_STAMPS")) {
-        // diagnostics (-DF5HIP_GEMM5_ABL builds, F5HIP_GEMM5_ABL=5): s_memrealtime stamps (100 MHz) of wave 0 (consumer) and wave 4 (loader) of every workgroup
-        const int maxg = 4096;
-        unsigned long long* d = b.get<unsigned long long>((size_t)maxg * 16);
-        if (d) {
-            (void)hipMemsetAsync(d, 0, sizeof(unsigned long long) * maxg * 16, st);
-            for (int rep = 0; rep < 3; rep++) {
-                GemmArgs g = args_for(Ws[rep % w_copies]);
-                g.stamps = d;
-                CK(run_gemm_n(prec, M_pad, g, Ws[rep % w_copies], EPI_GENERIC, false, 128, st));
-            }
-            (void)hipStreamSynchronize(st);
-            std::vector<unsigned long long> h((size_t)maxg * 16);
-            (void)hipMemcpy(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost);
-            unsigned long long tmin = ~0ull, tmax = 0;
-            int ng = 0;
-            for (int g2 = 0; g2 < maxg; g2++) if (h[(size_t)g2 * 16]) { ng = g2 + 1; tmin = std::min(tmin, h[(size_t)g2 * 16]); tmax = std::max(tmax, std::max(h[(size_t)g2 * 16 + 6], h[(size_t)g2 * 16 + 14])); }
-            const char* names[7] = {"start", "tile0 landed (loader)", "k-loop end", "E1 passed", "E2 passed (slab done)", "row phase issued", "stores drained"};
-            fprintf(stderr, "[gemm5 stamps] M %d N %d K %d: %d workgroups, first start -> last end %.2f us\n", M, N, K, ng, (tmax - tmin) * 0.01);
-            for (int w = 0; w < 2; w++)
-                for (int i = 0; i < 7; i++) {
-                    std::vector<double> v;
-                    for (int g2 = 0; g2 < ng; g2++) { const unsigned long long t = h[(size_t)g2 * 16 + w * 8 + i]; if (t) v.push_back((t - tmin) * 0.01); }
-                    if (v.empty()) continue;
-                    std::sort(v.begin(), v.end());
-                    fprintf(stderr, "[gemm5 stamps]   wave %d  %-26s min %6.2f  median %6.2f  max %6.2f us after the first workgroup started\n", w * 4, names[i], v.front(), v[v.size() / 2], v.back());
-                }
-        }
-    }
+    if (getenv("F5HIP_GEMM5_STAMPS"))
+        CK(gemm5_stamp_report(b, M, N, K, st, [&](unsigned long long* d, int rep) {
+            GemmArgs g = args_for(Ws[rep % w_copies]);
+            g.stamps = d;
+            return run_gemm_n(prec, M_pad, g, Ws[rep % w_copies], EPI_GENERIC, false, 128, st);
+        }));
     if (iters > 0 && avg_us) {
         // timing: the residual epilogue accumulates in place, so time into a scratch output
         float* scratch = b.get<float>((size_t)M * N);
@@ -152,6 +168,12 @@ extern "C" int f5hip_op_qkv(int32_t M, int32_t D, const float* a_dev, const floa
     (void)hipMemcpyAsync(bias, bias_dev, sizeof(float) * N, hipMemcpyDeviceToDevice, st);
     GemmArgs g = gemm_base(A, D, W, M);
     g.D = D; g.row_pos = pos; g.rope_cos = rc; g.rope_sin = rs; g.qk = (__bf16*)qk_dev; g.vt = (__bf16*)vt_dev; g.ldvt = M_pad;
+    if (getenv("F5HIP_GEMM5_STAMPS"))
+        CK(gemm5_stamp_report(b, M, N, D, st, [&](unsigned long long* d, int) {
+            GemmArgs g2 = g;
+            g2.stamps = d;
+            return run_gemm_n(prec, M_pad, g2, W, EPI_QKV, false, 128, st);
+        }));
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     for (int it = -1; it < iters; it++) {
