@@ -177,3 +177,32 @@ def test_layernorm_unit_op(rms):
         ref = (xd - mu) / (var + 1e-6).sqrt() * (1 + scale.double()) + shift.double()
         out = ops.layernorm(x.to(DEV), scale, shift, gain_off=1.0, eps=1e-6)
     assert _rel(out, ref) < 2e-6
+
+
+@pytest.mark.parametrize("impl", [4, 3])
+@pytest.mark.parametrize("lens,kv,heads", [((1404, 1404), None, 16), ((300, 50, 257), (300, 41, 200), 4), ((748,), None, 12), ((64,), (1,), 2),
+                                           ((2341, 2341), None, 16)])
+def test_attention_unit_op(impl, lens, kv, heads):
+    """Attention kernel alone vs fp64 softmax attention on the bf16-rounded operands (q after the 1/8 scale), incl. the key-padding mask
+    (F/model/modules.py:429-434), ragged sequences, tiles that overhang a sequence, and the C2 / C1 / C5 shapes."""
+    from tts_indic_server_f5_amd import ops
+    g = torch.Generator().manual_seed(sum(lens) + heads)
+    n, D = sum(lens), 64 * heads
+    q = torch.randn(n, D, generator=g) * 1.5
+    k = torch.randn(n, D, generator=g) * 1.5
+    v = torch.randn(n, D, generator=g)
+    out, _ = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), lens, kv, heads=heads, impl=impl)
+    qb, kb, vb = (q * 0.125).bfloat16().double(), k.bfloat16().double(), v.bfloat16().double()
+    o, refs = 0, []
+    for i, L in enumerate(lens):
+        kl = L if kv is None else kv[i]
+        qs, ks, vs = (t[o:o + L].view(L, heads, 64).transpose(0, 1) for t in (qb, kb, vb))
+        s = qs @ ks.transpose(1, 2)
+        s[:, :, kl:] = float("-inf")
+        refs.append((torch.softmax(s, dim=-1) @ vs).transpose(0, 1).reshape(L, D))
+        o += L
+    ref = torch.cat(refs)
+    # P is rounded to bf16 before the P V product (8 mantissa bits on probabilities <= 1); the output planes carry 16 bits
+    assert torch.isfinite(out).all()
+    assert (out.double().cpu() - ref).abs().max().item() < 2e-2
+    assert _rel(out, ref) < 4e-3

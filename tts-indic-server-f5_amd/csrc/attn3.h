@@ -59,8 +59,7 @@ static __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
 #pragma unroll
         for (int j = 0; j < P_HI; j++)
             if (j < P_LO || wave + NW * j < 16)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + kt * step[j]),
-                                                 (__attribute__((address_space(3))) void*)(dst + j * NW * 1024), 16, 0, 0);
+                attn_lds_dma16(src[j] + kt * step[j], dst + j * NW * 1024);   // (asm: keeps hipcc's lgkmcnt waits exact, see attn_common.h)
     };
     // this wave's pieces of a tile have landed when at most `newer` younger tiles of its own are in flight
     auto wait_landed = [&](int newer) {

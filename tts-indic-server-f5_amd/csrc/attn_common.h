@@ -19,3 +19,15 @@ F5_DEVICE int lds_off128(int row, int chunk) { return row * 128 + ((chunk ^ ((ro
 
 template <int N>
 F5_DEVICE void attn_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// One 1 KiB LDS-DMA piece (64 lanes x 16 B) through inline asm.  With the builtin (__builtin_amdgcn_global_load_lds) in the same loop as
+// the fragment reads, hipcc's wait-count model sees a FLAT-class instruction with an LDS operand ("pending flat": may return out of
+// order) and degrades every s_waitcnt lgkmcnt(N) of the loop to lgkmcnt(0) -- it then waits for the fragment reads it has just issued.
+// An asm statement is invisible to that model; it has no VGPR destination, and its completion is counted by hand (vmcnt).
+// M0 (the LDS destination) is compiler-reserved: saved and restored inside the statement.
+F5_DEVICE void attn_lds_dma16(const char* gsrc, char* lds_dst) {
+    const unsigned d = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)lds_dst);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(d) : "memory");
+}

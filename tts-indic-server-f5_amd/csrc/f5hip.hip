@@ -596,7 +596,11 @@ static int launch_attention(f5hip_dit* m, hipStream_t st) {
     else if (attn_impl == 2) hipLaunchKernelGGL(attn2_fwd_kernel, dim3((m->max_len + 255) / 256, c.heads, m->n_seq), dim3(512), 0, st, at);
     else
 #endif
-    if (hipError_t e = f5_launch_attn3(at, m->max_len, c.heads, m->n_seq, st); e != hipSuccess) { prof_end(PROF_ATTN, st); return fail(-7, "attention launch: %s", hipGetErrorString(e)); }
+    {
+        static const int attn_sel = getenv("F5HIP_ATTN") ? atoi(getenv("F5HIP_ATTN")) : 4;   // 3 = attn3 (round 1) for A/B
+        const hipError_t e = attn_sel == 3 ? f5_launch_attn3(at, m->max_len, c.heads, m->n_seq, st) : f5_launch_attn4(at, m->max_len, c.heads, m->n_seq, st);
+        if (e != hipSuccess) { prof_end(PROF_ATTN, st); return fail(-7, "attention launch: %s", hipGetErrorString(e)); }
+    }
     prof_end(PROF_ATTN, st);
     CKL("attention");
     return 0;

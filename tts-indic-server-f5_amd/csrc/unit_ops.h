@@ -199,3 +199,71 @@ extern "C" int f5hip_op_layernorm(int32_t M, int32_t D, const float* x_dev, cons
     CK(run_ln(ln, st));
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------- attention unit op
+__global__ __launch_bounds__(256) void op_pack_qkv_kernel(const float* q, const float* k, const float* v, int D, const int* row_src, int M_pad,
+                                                          __bf16* qk, __bf16* vt) {
+    const int row = blockIdx.x, src = row_src[row];
+    for (int c = threadIdx.x; c < D; c += 256) {
+        const float qv = src >= 0 ? q[(size_t)src * D + c] * 0.125f : 0.0f;   // q is pre-scaled by 1/8 (QKV epilogue; exact in bf16)
+        const float kv = src >= 0 ? k[(size_t)src * D + c] : 0.0f;
+        const float vv = src >= 0 ? v[(size_t)src * D + c] : 0.0f;
+        qk[(size_t)row * 2 * D + c] = (__bf16)qv;
+        qk[(size_t)row * 2 * D + D + c] = (__bf16)kv;
+        vt[(size_t)c * M_pad + row] = (__bf16)vv;
+    }
+}
+__global__ __launch_bounds__(256) void op_unpack_planes_kernel(const __bf16* hi, const __bf16* lo, int D, const int* frame_row, float* out) {
+    const int f = blockIdx.x, row = frame_row[f];
+    for (int c = threadIdx.x; c < D; c += 256) out[(size_t)f * D + c] = (float)hi[(size_t)row * D + c] + (float)lo[(size_t)row * D + c];
+}
+
+// softmax(q k^T / 8 + key-padding mask) v per (sequence, head), head dim 64 (F/model/modules.py:424-436): q / k / v fp32 [sum(seq_len)][64 heads]
+// are rounded to bf16 like the QKV epilogue's outputs (q after the 1/8 scale); out fp32 [sum(seq_len)][64 heads] = split-bf16 planes summed.
+// impl 4 = attn4 (production), 3 = attn3 (round 1).
+extern "C" int f5hip_op_attention(int32_t n_seq, const int32_t* seq_len, const int32_t* kv_len, int32_t heads, const float* q_dev,
+                                  const float* k_dev, const float* v_dev, float* out_dev, int32_t impl, int32_t iters, double* avg_us, void* stream) {
+    if (n_seq <= 0 || !seq_len || heads <= 0 || !q_dev || !k_dev || !v_dev || !out_dev || (impl != 3 && impl != 4)) return fail(-1, "op_attention: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    const int D = heads * 64;
+    int M_pad = 0, F = 0, max_len = 0;
+    for (int i = 0; i < n_seq; i++) {
+        if (seq_len[i] <= 0 || seq_len[i] > 4096 || (kv_len && (kv_len[i] <= 0 || kv_len[i] > seq_len[i]))) return fail(-1, "op_attention: bad lengths");
+        M_pad += (seq_len[i] + 127) / 128 * 128; F += seq_len[i]; max_len = std::max(max_len, (int)seq_len[i]);
+    }
+    std::vector<int> row_src(M_pad, -1), frame_row(F), meta(3 * n_seq);
+    for (int i = 0, r0 = 0, f0 = 0; i < n_seq; i++) {
+        meta[i] = r0; meta[n_seq + i] = seq_len[i]; meta[2 * n_seq + i] = kv_len ? kv_len[i] : seq_len[i];
+        for (int j = 0; j < seq_len[i]; j++) { row_src[r0 + j] = f0 + j; frame_row[f0 + j] = r0 + j; }
+        r0 += (seq_len[i] + 127) / 128 * 128; f0 += seq_len[i];
+    }
+    OpBufs b;
+    __bf16* qk = b.get<__bf16>((size_t)(M_pad + 256) * 2 * D); __bf16* vt = b.get<__bf16>((size_t)D * M_pad);
+    __bf16* ohi = b.get<__bf16>((size_t)M_pad * D); __bf16* olo = b.get<__bf16>((size_t)M_pad * D);
+    int* d_rs = b.get<int>(M_pad); int* d_fr = b.get<int>(F); int* d_meta = b.get<int>(3 * n_seq);
+    if (!qk || !vt || !ohi || !olo || !d_rs || !d_fr || !d_meta) return fail(-5, "op_attention: hipMalloc");
+    if (hipMemcpyAsync(d_rs, row_src.data(), sizeof(int) * M_pad, hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipMemcpyAsync(d_fr, frame_row.data(), sizeof(int) * F, hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipMemcpyAsync(d_meta, meta.data(), sizeof(int) * 3 * n_seq, hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipMemsetAsync(qk, 0, sizeof(__bf16) * (size_t)(M_pad + 256) * 2 * D, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+        return fail(-6, "op_attention: upload");
+    hipLaunchKernelGGL(op_pack_qkv_kernel, dim3(M_pad), dim3(256), 0, st, q_dev, k_dev, v_dev, D, d_rs, M_pad, qk, vt);
+    AttnArgs at; memset(&at, 0, sizeof(at));
+    at.qk = qk; at.vt = vt; at.D = D; at.ldvt = M_pad; at.seq_row0 = d_meta; at.seq_len = d_meta + n_seq; at.seq_kvlen = d_meta + 2 * n_seq;
+    at.out_hi = ohi; at.out_lo = olo;
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    hipError_t e = hipSuccess;
+    for (int it = -1; it < iters && e == hipSuccess; it++) {
+        if (it == 0) (void)hipEventRecord(e0, st);
+        e = impl == 3 ? f5_launch_attn3(at, max_len, heads, n_seq, st) : f5_launch_attn4(at, max_len, heads, n_seq, st);
+    }
+    (void)hipEventRecord(e1, st);
+    (void)hipEventSynchronize(e1);
+    if (iters > 0 && avg_us) { float ms = 0.f; (void)hipEventElapsedTime(&ms, e0, e1); *avg_us = (double)ms * 1e3 / iters; }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (e != hipSuccess) return fail(-7, "op_attention launch: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(op_unpack_planes_kernel, dim3(F), dim3(256), 0, st, ohi, olo, D, d_fr, out_dev);
+    if (hipStreamSynchronize(st) != hipSuccess) return fail(-7, "op_attention: %s", hipGetErrorString(hipGetLastError()));
+    return 0;
+}

@@ -62,3 +62,16 @@ def layernorm(x, scale, shift, *, gain_off=1.0, eps=1e-6, rms=False):
     _lib.check(_lib.lib().f5hip_op_layernorm(M, D, _p(x), _p(scale), _p(shift), float(gain_off), float(eps), int(rms), _p(out),
                                              _lib.current_stream_ptr()), "f5hip_op_layernorm")
     return out
+
+
+def attention(q, k, v, seq_len, kv_len=None, *, heads, impl=4, iters=0):
+    """softmax(q k^T / 8 + key mask) v per (sequence, head); q / k / v fp32 [sum(seq_len), 64 * heads] packed.  Returns (out, avg_us)."""
+    dev = q.device
+    q, k, v = (_f32(t, dev) for t in (q, k, v))
+    out = torch.empty_like(q)
+    sl = np.ascontiguousarray(np.asarray(seq_len, dtype=np.int32))
+    kl = None if kv_len is None else np.ascontiguousarray(np.asarray(kv_len, dtype=np.int32))
+    us = C.c_double(0.0)
+    _lib.check(_lib.lib().f5hip_op_attention(len(sl), _p(sl), _p(kl), heads, _p(q), _p(k), _p(v), _p(out), impl, iters, C.byref(us),
+                                             _lib.current_stream_ptr()), "f5hip_op_attention")
+    return out, us.value
