@@ -122,7 +122,7 @@ int f5hip_op_qkv(int32_t M, int32_t D, const float* a_dev, const float* w_dev, c
 /* f5hip_op_attention: softmax(q k^T / 8 + key-padding mask) v per (sequence, head), head dim 64 -- F.scaled_dot_product_attention with the
  *   reference's [b, 1, 1, n] key mask (F/model/modules.py:424-436).  q_dev / k_dev / v_dev / out_dev fp32 [sum(seq_len)][64 heads], sequences
  *   packed back to back; kv_len[i] <= seq_len[i] valid keys (NULL: all).  Operands are rounded to bf16 like the QKV epilogue's outputs.
- *   impl 4 = the production kernel (attn4), 3 = the round-1 kernel kept for A/B. */
+ *   impl 3 = the production kernel (attn3); 4 = the experimental unequal-wave kernel (attn3 unless the library was built with experiments). */
 int f5hip_op_attention(int32_t n_seq, const int32_t* seq_len, const int32_t* kv_len, int32_t heads, const float* q_dev, const float* k_dev,
                        const float* v_dev, float* out_dev, int32_t impl, int32_t iters, double* avg_us, void* stream);
 /* f5hip_op_layernorm: y = LN(x) * (gain_off + scale) + shift (AdaLN: gain_off 1; affine LN: gain_off 0; F/model/modules.py:285-290),

@@ -26,8 +26,10 @@ def _deps(path: str, seen: set[str] | None = None) -> set[str]:
     """The file and everything it includes with "...", recursively (conditional includes count as dependencies too)."""
     seen = set() if seen is None else seen
     path = os.path.normpath(path)
-    if path in seen or not os.path.exists(path):
+    if path in seen:
         return seen
+    if not os.path.exists(path):
+        raise FileNotFoundError(f"{path}: included by a translation unit of libf5hip but missing")
     seen.add(path)
     with open(path, encoding="utf-8") as f:
         for inc in _INC.findall(f.read()):

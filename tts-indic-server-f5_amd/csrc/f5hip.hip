@@ -597,8 +597,8 @@ static int launch_attention(f5hip_dit* m, hipStream_t st) {
     else
 #endif
     {
-        static const int attn_sel = getenv("F5HIP_ATTN") ? atoi(getenv("F5HIP_ATTN")) : 4;   // 3 = attn3 (round 1) for A/B
-        const hipError_t e = attn_sel == 3 ? f5_launch_attn3(at, m->max_len, c.heads, m->n_seq, st) : f5_launch_attn4(at, m->max_len, c.heads, m->n_seq, st);
+        static const int attn_sel = getenv("F5HIP_ATTN") ? atoi(getenv("F5HIP_ATTN")) : 3;   // 4 = experiments/attn4.h (A/B in -DF5HIP_EXPERIMENTS builds)
+        const hipError_t e = attn_sel == 4 ? f5_launch_attn4(at, m->max_len, c.heads, m->n_seq, st) : f5_launch_attn3(at, m->max_len, c.heads, m->n_seq, st);
         if (e != hipSuccess) { prof_end(PROF_ATTN, st); return fail(-7, "attention launch: %s", hipGetErrorString(e)); }
     }
     prof_end(PROF_ATTN, st);

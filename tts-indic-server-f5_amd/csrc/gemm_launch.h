@@ -15,7 +15,7 @@ hipError_t f5_launch_gemm5_generic(const GemmArgs& a, int rb, int cb, int n_pad,
 hipError_t f5_launch_gemm5_qkv(const GemmArgs& a, int rb, int cb, int n_pad, hipStream_t st);
 // attn3.h: flash attention forward, 256 queries per workgroup
 hipError_t f5_launch_attn3(const AttnArgs& a, int max_len, int heads, int n_seq, hipStream_t st);
-// attn4.h: flash attention forward, 16 x 16 x 32 MFMA, 32 / 48 queries per compute wave, one compute wave per SIMD (production)
+// experiments/attn4.h (unequal-height waves, 16 x 16 x 32 MFMA; attn3 unless built with -DF5HIP_EXPERIMENTS)
 hipError_t f5_launch_attn4(const AttnArgs& a, int max_len, int heads, int n_seq, hipStream_t st);
 
 // gemm5 tile choice: fewest operand bytes per CU over the whole launch = rounds on the 256 CUs x (BM + BN); ties -> the larger tile.

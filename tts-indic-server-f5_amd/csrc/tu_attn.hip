@@ -1,6 +1,8 @@
 // translation unit: attention forward (attn3.h)
 #include "attn3.h"
-#include "attn4.h"
+#ifdef F5HIP_EXPERIMENTS
+#include "experiments/attn4.h"
+#endif
 #include "gemm_launch.h"
 
 // Query-tile height 32 NW with NW in {4, 6, 8}: fewest (rounds on the 256 CUs) x (work per workgroup); ties -> the larger tile (fewer
@@ -20,17 +22,16 @@ hipError_t f5_launch_attn3(const AttnArgs& a, int max_len, int heads, int n_seq,
     return hipGetLastError();
 }
 
-// attn4: waves 0-3 own 32 queries, waves 4-7 own 16 (192 per workgroup, 48 per SIMD).  Measured (tools/attn_bench.py,
-// profiles/r02_attn_bench.txt): per query the 16 x 16 x 32 formulation is ~1.3x slower than attn3's 32 x 32 x 16 one, so it only pays
-// where the 192-query tile removes a whole round's worth of imbalance -- C2: 256 workgroups in one round, 41 us against 45 -- and
-// attn3 stays the kernel for every other shape (C3 share: 237 us against 308).
+// attn4 (experiments/attn4.h, -DF5HIP_EXPERIMENTS builds only): 16 x 16 x 32 MFMA blocks, waves 0-3 own 32 queries and waves 4-7 own 16
+// (192 per workgroup, 48 per SIMD: exactly 256 workgroups at C2).  Measured and NOT used (profiles/r02_attn_bench.txt): per query the
+// 16 x 16 formulation is ~1.3x slower than attn3's 32 x 32 x 16 one (C3 share with equal wave heights: 308 us against 237), the balanced
+// C2 launch wins 8 % in isolation (41 us against 45) but 0.5 % end to end (98.3 ms against 98.85), and a kernel choice that depends on
+// the batch shape breaks the bit-for-bit "batch of copies == single utterance" property.  Without the experiments flag this is attn3.
 hipError_t f5_launch_attn4(const AttnArgs& a, int max_len, int heads, int n_seq, hipStream_t st) {
-    const long long per = (long long)heads * n_seq;
-    const long long wg192 = (long long)((max_len + 191) / 192) * per, wg256 = (long long)((max_len + 255) / 256) * per;
-    const long long cost192 = ((wg192 + 255) / 256) * 3 * 13, cost256 = ((wg256 + 255) / 256) * 4 * 10;   // x 1.3 for the 16 x 16 formulation
-    if (cost192 < cost256) {
-        hipLaunchKernelGGL((attn4_fwd_kernel<2, 1>), dim3((max_len + 191) / 192, heads, n_seq), dim3(512), 0, st, a);
-        return hipGetLastError();
-    }
+#ifdef F5HIP_EXPERIMENTS
+    hipLaunchKernelGGL((attn4_fwd_kernel<2, 1>), dim3((max_len + 191) / 192, heads, n_seq), dim3(512), 0, st, a);
+    return hipGetLastError();
+#else
     return f5_launch_attn3(a, max_len, heads, n_seq, st);
+#endif
 }

@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256) void op_unpack_planes_kernel(const __bf16* hi,
 
 // softmax(q k^T / 8 + key-padding mask) v per (sequence, head), head dim 64 (F/model/modules.py:424-436): q / k / v fp32 [sum(seq_len)][64 heads]
 // are rounded to bf16 like the QKV epilogue's outputs (q after the 1/8 scale); out fp32 [sum(seq_len)][64 heads] = split-bf16 planes summed.
-// impl 4 = attn4 (production), 3 = attn3 (round 1).
+// impl 3 = attn3 (production), 4 = experiments/attn4.h (attn3 unless built with -DF5HIP_EXPERIMENTS).
 extern "C" int f5hip_op_attention(int32_t n_seq, const int32_t* seq_len, const int32_t* kv_len, int32_t heads, const float* q_dev,
                                   const float* k_dev, const float* v_dev, float* out_dev, int32_t impl, int32_t iters, double* avg_us, void* stream) {
     if (n_seq <= 0 || !seq_len || heads <= 0 || !q_dev || !k_dev || !v_dev || !out_dev || (impl != 3 && impl != 4)) return fail(-1, "op_attention: bad argument");

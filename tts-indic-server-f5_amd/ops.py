@@ -64,7 +64,7 @@ def layernorm(x, scale, shift, *, gain_off=1.0, eps=1e-6, rms=False):
     return out
 
 
-def attention(q, k, v, seq_len, kv_len=None, *, heads, impl=4, iters=0):
+def attention(q, k, v, seq_len, kv_len=None, *, heads, impl=3, iters=0):
     """softmax(q k^T / 8 + key mask) v per (sequence, head); q / k / v fp32 [sum(seq_len), 64 * heads] packed.  Returns (out, avg_us)."""
     dev = q.device
     q, k, v = (_f32(t, dev) for t in (q, k, v))
