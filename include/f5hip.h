@@ -160,7 +160,9 @@ typedef struct f5hip_bigvgan_config {
     int32_t upsample_initial_channel;
     int32_t resblock_kernel_sizes[3];
     int32_t resblock_dilations[9];   /* [kernel index][dilation index] */
-    int32_t gemm_planes;
+    int32_t gemm_planes;             /* conv operand precision, fp32 accumulation: 2 = split bf16, three MFMAs per product (the parity
+                                        mode: 1.5e-5 max on the waveform); 3 = one fp16 plane (fast mode, NOT within the 1e-4 parity
+                                        bound: ~1e-3 max / 2e-4 rms measured); 1 = plain bf16 */
 } f5hip_bigvgan_config;
 typedef struct f5hip_bigvgan f5hip_bigvgan;
 

@@ -124,6 +124,11 @@ def test_c4_bigvgan_full_geometry_936_frames():
     assert d.max().item() < 1e-4
     many = voc(mel[:1].expand(16, -1, -1))
     assert (many - got[:1]).abs().max().item() < 2e-6          # B = 16 copies == single (batch composition never leaks between items)
+    # the fp16 fast mode (gemm_planes=3) at the same geometry: outside the 1e-4 parity bound by design, pinned at its measured level
+    fast = F5HipBigVGAN(sd, gemm_planes=3)(mel)
+    df = (fast.cpu() - ref).abs()
+    print(f"[parity] C4 BigVGAN T=936 B=2 fp16 fast mode: max err {df.max():.3e} rms {df.pow(2).mean().sqrt():.3e}")
+    assert df.max().item() < 3e-3 and df.pow(2).mean().sqrt().item() < 5e-4
 
 
 # ---------------------------------------------------------------------------------------------------------------- C5

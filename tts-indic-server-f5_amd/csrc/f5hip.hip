@@ -432,7 +432,12 @@ static int run_gemm_n(int nsplit, int mp, GemmArgs& a, const PackedW& W, int epi
     } else
 #endif
     if (nsplit == 3) {   // fp16 operands, one plane each
-        if (conv) { prof_end(PROF_GEMM, st); return fail(-7, "gemm: fp16 operands are not built for the implicit-GEMM convolution"); }
+        if (conv) {   // implicit-GEMM convolution (BigVGAN in fp16 mode): register-staged kernel
+            e = f5_launch_gemm_reg(3, bn, true, epi, a, mp, np, st);
+            prof_end(PROF_GEMM, st);
+            if (e != hipSuccess) return fail(-7, "gemm launch: %s", hipGetErrorString(e));
+            return 0;
+        }
         const Gemm5Choice c5 = gemm5_choose(a.M, np);
         if ((g_gemm_impl == 0 || g_gemm_impl == 5) && a.K % 64 == 0 && c5.rb) {
             e = epi == EPI_QKV ? f5_launch_gemm5_qkv(a, c5.rb, c5.cb, np, st) : f5_launch_gemm5_generic(a, c5.rb, c5.cb, np, st);

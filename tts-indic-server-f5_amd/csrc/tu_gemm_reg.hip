@@ -4,7 +4,9 @@
 
 hipError_t f5_launch_gemm_reg(int prec, int bn, bool conv, int epi, const GemmArgs& a, int m_pad, int n_pad, hipStream_t st) {
     if (prec == 3) {
-        if (conv || bn != 128) return hipErrorInvalidValue;
+        if (conv && bn == 64) return launch_gemm_t<3, 64, true, EPI_GENERIC>(a, m_pad, n_pad, st);
+        if (conv) return launch_gemm_t<3, 128, true, EPI_GENERIC>(a, m_pad, n_pad, st);
+        if (bn != 128) return hipErrorInvalidValue;
         return epi == EPI_QKV ? launch_gemm_t<3, 128, false, EPI_QKV>(a, m_pad, n_pad, st) : launch_gemm_t<3, 128, false, EPI_GENERIC>(a, m_pad, n_pad, st);
     }
     if (prec == 2) {
