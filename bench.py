@@ -51,6 +51,8 @@ def parse_args(argv=None):
     ap.add_argument("--total-batch", type=int, default=64, help="strong mode: utterances per step over all GPUs (64 = BASELINE configs[2])")
     ap.add_argument("--ragged", action="store_true", help="generated lengths U(6 s, 14 s) instead of 10 s (SURVEY section 8(d))")
     ap.add_argument("--vocoder", default="vocos", choices=["vocos", "bigvgan"], help="bigvgan = BASELINE configs[3]")
+    ap.add_argument("--vocoder-planes", type=int, default=2, choices=[1, 2, 3],
+                    help="BigVGAN conv operand precision: 2 = split bf16 (parity mode, default), 3 = one fp16 plane (fast mode, outside the 1e-4 waveform bound)")
     return ap.parse_args(argv)
 
 
@@ -180,7 +182,7 @@ def run_rank(args):
     bigv = None
     if args.vocoder == "bigvgan":
         from tts_indic_server_f5_amd.vocoder import F5HipBigVGAN
-        bigv = F5HipBigVGAN(synth.bigvgan_state_dict(), gemm_planes=min(args.gemm_planes, 2), device=dev)
+        bigv = F5HipBigVGAN(synth.bigvgan_state_dict(), gemm_planes=args.vocoder_planes, device=dev)
 
     # ---- the units of one step: (global index, total frames).  Every rank derives the same list and takes its share.
     n_units = args.total_batch if args.mode == "strong" else args.batch * world
@@ -277,7 +279,7 @@ def run_rank(args):
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": args.mode,
             "vs_baseline": None, "dtype": "fp16/bf16 MFMA, fp32 accumulate" if args.gemm_planes == 3 else "bf16", "data": "synthetic",
             "rtf": round(dt / args.steps / audio_s, 6),
-            "config": {"workload": f"F5-TTS-Base, 32 NFE + CFG=2.0 + sway -1, {'BigVGAN' if bigv is not None else 'Vocos'}, {n_units} x "
+            "config": {"workload": f"F5-TTS-Base, 32 NFE + CFG=2.0 + sway -1, {('BigVGAN (' + {1: 'bf16', 2: 'split bf16', 3: 'fp16 fast mode'}[args.vocoder_planes] + ' convs)') if bigv is not None else 'Vocos'}, {n_units} x "
                                    f"{'U(6 s, 14 s)' if args.ragged else '10 s'} utterance{'s' if n_units > 1 else ''} per step over {n_gpus} GPU{'s' if n_gpus > 1 else ''}"
                                    f" ({B} on rank 0; N=1404 = 468 reference + 936 generated frames at 10 s)",
                        "gemm_mode": GEMM_MODES[args.gemm_planes],
