@@ -90,6 +90,11 @@ int f5hip_cfm_sample_masked(f5hip_dit* m, int32_t n_utt, const int32_t* dur, con
                             const uint8_t* cond_mask, const int32_t* text, int32_t nt_max, const float* y0_dev,
                             const float* t_grid, int32_t steps, float cfg_strength, float* out_dev, void* stream);
 
+/* The fixed-grid solver both sample calls use: replaces CFM(odeint_kwargs=dict(method=...)) (F/model/cfm.py:37-41,72,200; set from
+ * load_model(ode_method=...), F/infer/utils_infer.py:251).  0 = "euler" (default): x += dt * v(t_i, x).  1 = "midpoint":
+ * x += dt * v(t_i + dt / 2, x + dt / 2 * v(t_i, x)), two backbone evaluations per step, at most 64 steps per call. */
+int f5hip_dit_set_ode_method(f5hip_dit* m, int32_t method);
+
 /* Per-kernel timing of the last f5hip_cfm_sample call when profiling was enabled with
  * f5hip_set_profiling(1): average milliseconds per launch of the named kernel class
  * ("gemm", "attn", "ln", "other") measured with HIP events on the launch stream, and launch counts. */

@@ -83,6 +83,24 @@ def euler_odeint(fn, y0: torch.Tensor, t: torch.Tensor, keep_trajectory: bool = 
     return y
 
 
+def midpoint_odeint(fn, y0: torch.Tensor, t: torch.Tensor, keep_trajectory: bool = True):
+    """torchdiffeq 0.2.5 odeint(method='midpoint') on the fixed grid t (the alternative named at F/model/cfm.py:40 and passed
+    through load_model(ode_method=...), F/infer/utils_infer.py:251).
+
+    y_{i+1} = y_i + dt * fn(t_i + dt / 2, y_i + dt / 2 * fn(t_i, y_i)),  dt = t_{i+1} - t_i."""
+    ys = [y0]
+    y = y0
+    for i in range(t.numel() - 1):
+        dt = t[i + 1] - t[i]
+        half = 0.5 * dt
+        y = y + dt * fn(t[i] + half, y + half * fn(t[i], y))
+        if keep_trajectory:
+            ys.append(y)
+    if keep_trajectory:
+        return torch.stack(ys)
+    return y
+
+
 # ----------------------------------------------------------------------------
 # reference-owned math (pinned by tests/golden fixtures)
 # ----------------------------------------------------------------------------
@@ -250,7 +268,7 @@ def make_noise(durations, mel_dim: int, seed: int | None, y0=None) -> torch.Tens
 @torch.no_grad()
 def cfm_sample(sd, cfg: DiTConfig, cond: torch.Tensor, text: torch.Tensor, duration, *, lens=None, steps=32,
                cfg_strength=1.0, sway_sampling_coef=None, seed=None, max_duration=4096, y0=None,
-               edit_mask=None, no_ref_audio=False, forward_fn=None, keep_trajectory=True):
+               edit_mask=None, no_ref_audio=False, forward_fn=None, keep_trajectory=True, method="euler"):
     """CFM.sample, F/model/cfm.py:82-210, for mel `cond` [b, n, 100] and int `text` [b, nt] (-1 padded).
 
     `forward_fn` lets a test substitute another backbone (UNetT oracle, or a
@@ -285,7 +303,9 @@ def cfm_sample(sd, cfg: DiTConfig, cond: torch.Tensor, text: torch.Tensor, durat
 
     y0 = make_noise(duration, cfg.mel_dim, seed, y0)
     t = sway_time_grid(steps, sway_sampling_coef)
-    traj = euler_odeint(fn, y0, t, keep_trajectory=keep_trajectory)
+    if method not in ("euler", "midpoint"):
+        raise ValueError(f"unknown ODE method {method!r}")
+    traj = (euler_odeint if method == "euler" else midpoint_odeint)(fn, y0, t, keep_trajectory=keep_trajectory)
     last = traj[-1] if keep_trajectory else traj
     out = torch.where(cond_mask, cond, last)
     return out, (traj if keep_trajectory else None)

@@ -265,6 +265,30 @@ def test_lens_no_ref_audio_and_duplicate_test_branches(tiny_model):
     assert _report("duplicate_test", got, ref) < 1e-3
 
 
+@pytest.mark.parametrize("planes", [2, 3], ids=["bf16x3", "mixed_f16"])
+def test_midpoint_solver_vs_oracle(planes):
+    """CFM(odeint_kwargs=dict(method="midpoint")) (cfm.py:37-41,200): two backbone evaluations per step, time embeddings at t_i and t_i + dt/2.
+    torchdiffeq is absent, so the step rule itself is pinned by the closed-form test in tests/test_oracle_dit.py (parity unpinned leaf)."""
+    from tts_indic_server_f5_amd._lib import F5HipError
+    from tts_indic_server_f5_amd.model import DiTArch, F5HipModel
+    sd, cfg = synth.dit_state_dict(**TINY), O.DiTConfig(**TINY)
+    model = F5HipModel(DiTArch(**TINY), sd, gemm_planes=planes, odeint_kwargs=dict(method="midpoint"))
+    g = torch.Generator().manual_seed(63)
+    cond = torch.randn(1, 24, 100, generator=g)
+    text = torch.randint(0, 40, (1, 12), generator=g)
+    y0 = torch.randn(1, 60, 100, generator=g)
+    kw = dict(steps=6, cfg_strength=2.0, sway_sampling_coef=-1.0, y0=y0)
+    ref, _ = O.cfm_sample(sd, cfg, cond, text, 60, keep_trajectory=False, method="midpoint", **kw)
+    eul, _ = O.cfm_sample(sd, cfg, cond, text, 60, keep_trajectory=False, **kw)
+    got, _ = model.sample(cond, text, 60, **kw)
+    assert _report("midpoint sample", got, ref) < 1e-3
+    assert (ref - eul)[:, 24:].pow(2).mean().sqrt() > 1e-2          # a different trajectory from Euler, not a relabelled one
+    with pytest.raises(F5HipError, match="midpoint"):
+        model.sample(cond, text, 60, steps=65, cfg_strength=2.0, y0=y0)
+    with pytest.raises(ValueError):
+        F5HipModel(DiTArch(**TINY), sd, odeint_kwargs=dict(method="dopri5"))
+
+
 def test_attention_tile_overhanging_the_workspace(tiny_model):
     """A last sequence whose final 256-query attention tile reaches past its 128-row padding (n % 256 in 1..128): those query rows are
     loaded from the slack rows of the workspace and never stored (the round-1 aborts came from exactly this read before the slack existed)."""

@@ -98,3 +98,40 @@ def test_speech_endpoint_on_hip_path(tmp_path):
     err = float(np.max(np.abs(pcm.astype(np.float64) / 32768.0 - w_ref)))
     print(f"[parity] /v1/audio/speech vs oracle pipeline: max err {err:.3e} (16-bit step 3.1e-5), n={len(pcm)}")
     assert err < 1e-4 + 1.0 / 32768
+
+
+def test_infer_requests_two_voices_one_batch():
+    """`infer.infer_requests` on the HIP objects: requests with DIFFERENT reference voices (different prompt lengths, one below the
+    rms floor) are sampled as one library call, every unit with its own prompt length (`lens`) and batch-1 semantics; each result equals
+    the request run alone on the same objects (2e-5: batch composition does not leak) and the CPU oracle pipeline (1e-3 / 1e-4).
+    Also the multi-voice `[tag]` front-end (F/infer/infer_cli.py:181-208) over the same batch path."""
+    from tts_indic_server_f5_amd.model import DiTArch, F5HipModel
+    from tts_indic_server_f5_amd.vocoder import F5HipVocos
+    sd, vsd = synth.dit_state_dict(**ARCH), synth.vocos_state_dict()
+    kw = dict(nfe_step=8, cfg_strength=2.0, sway_sampling_coef=-1.0)
+    va = (synth.ref_audio(24000 * 2, amp=0.15), 24000)
+    vb = (synth.ref_audio(int(24000 * 1.4), seed=9, amp=0.03), 24000)
+    reqs = [(va, "Some call me nature.", "I do not care what you call me. I have been a silent spectator, watching species evolve."),
+            (vb, "Others say mother.", "Always remember, I endure."),
+            (va, "Some call me nature.", "Short.")]
+    model, voc = F5HipModel(DiTArch(**ARCH), sd, vocab_char_map=VOCAB), F5HipVocos(vsd)
+    torch.manual_seed(77)
+    batch = infer.infer_requests(reqs, model, voc, device="cuda", **kw)
+    torch.manual_seed(77)
+    alone = [infer.infer_process(a, rt, gt, model, voc, device="cuda", **kw) for a, rt, gt in reqs]
+    torch.manual_seed(77)
+    oracle = [infer.infer_process(a, rt, gt, OracleModel(sd), OracleVocoder(vsd), **kw) for a, rt, gt in reqs]
+    for i, ((w, sr, s), (w1, _, s1), (w0, _, s0)) in enumerate(zip(batch, alone, oracle)):
+        assert sr == 24000 and w.shape == w1.shape == w0.shape and s.shape == s1.shape == s0.shape
+        d_alone, d_mel, d_wav = float(np.abs(w - w1).max()), float(np.sqrt(np.mean((s - s0) ** 2))), float(np.abs(w - w0).max())
+        print(f"[parity] infer_requests item {i}: vs alone wave {d_alone:.3e}; vs oracle mel rms {d_mel:.3e} wave max {d_wav:.3e}")
+        assert d_alone < 2e-5 and float(np.sqrt(np.mean((s - s1) ** 2))) < 2e-5
+        assert d_mel < 1e-3 and d_wav < 1e-4
+    voices = {"main": dict(ref_audio=va, ref_text="Some call me nature."), "b": dict(ref_audio=vb, ref_text="Others say mother.")}
+    script = "I do not care. [b] Always remember, I endure. [main] Short."
+    torch.manual_seed(78)
+    w, sr, specs = infer.infer_multi_voice(script, voices, model, voc, device="cuda", **kw)
+    torch.manual_seed(78)
+    parts = [infer.infer_process(voices[v]["ref_audio"], voices[v]["ref_text"], t, model, voc, device="cuda", **kw)[0]
+             for v, t in infer.split_voice_tags(script, voices)]
+    assert len(specs) == 3 and float(np.abs(w - np.concatenate(parts)).max()) < 2e-5

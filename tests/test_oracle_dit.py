@@ -105,6 +105,22 @@ def test_euler_closed_form():
     assert torch.allclose(y, expect.expand(3), atol=1e-6)
 
 
+def test_midpoint_closed_form():
+    """dy/dt = a y: one explicit-midpoint step multiplies y by 1 + a dt + (a dt)^2 / 2; second order, so closer to exp(a) than Euler."""
+    a = -0.7
+    t = O.sway_time_grid(16, -1.0)
+    y = O.midpoint_odeint(lambda tt, yy: a * yy, torch.ones(3), t, keep_trajectory=False)
+    dt = t[1:] - t[:-1]
+    expect = torch.prod(1 + a * dt + 0.5 * (a * dt) ** 2)
+    assert torch.allclose(y, expect.expand(3), atol=1e-6)
+    e = O.euler_odeint(lambda tt, yy: a * yy, torch.ones(3), t, keep_trajectory=False)
+    exact = torch.exp(torch.tensor(a))
+    assert (y[0] - exact).abs() < 0.1 * (e[0] - exact).abs()
+    # time-dependent field dy/dt = 2 t: the midpoint rule integrates it exactly on any grid
+    y2 = O.midpoint_odeint(lambda tt, yy: 2 * tt * torch.ones_like(yy), torch.zeros(2), t, keep_trajectory=False)
+    assert torch.allclose(y2, torch.ones(2), atol=1e-6)
+
+
 def test_sway_grid_endpoints_monotone():
     for s in (None, -1.0, 0.5):
         t = O.sway_time_grid(32, s)

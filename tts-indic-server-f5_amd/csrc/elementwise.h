@@ -182,7 +182,9 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* x, int ldx
 //   v = p + (p - p0) * cfg ;  x += dt * v
 // pred: [M_pad][ldp] rows of the conditional branch at row_c[u], unconditional at row_u[u] (or -1).
 // Also refreshes the split-bf16 copy of x that feeds the next step's input projection for both branches.
-__global__ __launch_bounds__(128) void cfg_euler_kernel(float* xstate /*[U][mel]*/, int mel, int U, const float* pred,
+// xout = xbase + dt * v: xout == xbase for an Euler step; the midpoint rule writes its half step to a scratch state and takes the full
+// step from the untouched xbase.
+__global__ __launch_bounds__(128) void cfg_euler_kernel(float* xout /*[U][mel]*/, const float* xbase, int mel, int U, const float* pred,
                                                         int ldp, const int* urow_c, const int* urow_u, float cfg,
                                                         float dt, __bf16* xs_hi, __bf16* xs_lo, int ldx) {
     const int u = blockIdx.x;
@@ -193,8 +195,8 @@ __global__ __launch_bounds__(128) void cfg_euler_kernel(float* xstate /*[U][mel]
     const float pc = pred[(size_t)rc * ldp + c];
     float v = pc;
     if (ru >= 0) v = pc + (pc - pred[(size_t)ru * ldp + c]) * cfg;
-    const float xn = xstate[(size_t)u * mel + c] + dt * v;
-    xstate[(size_t)u * mel + c] = xn;
+    const float xn = xbase[(size_t)u * mel + c] + dt * v;
+    xout[(size_t)u * mel + c] = xn;
     __bf16 hi, lo;
     split_bf16(xn, hi, lo);
     xs_hi[(size_t)rc * ldx + c] = hi;

@@ -56,7 +56,8 @@ struct f5hip_dit {
     int cap_rows = 0, cap_frames = 0, cap_seq = 0;
     DevBuf ws;   // one arena, carved below
     float *h = nullptr, *h0 = nullptr, *ce = nullptr, *pred = nullptr, *te = nullptr, *ty = nullptr, *gx = nullptr,
-          *mod = nullptr, *xstate = nullptr, *temb = nullptr;
+          *mod = nullptr, *xstate = nullptr, *xmid = nullptr, *temb = nullptr;
+    int ode_method = 0;   // 0 = Euler, 1 = explicit midpoint (f5hip_dit_set_ode_method)
     std::vector<Plane2> skipbuf;
     Plane2 hn, c1, ao, ff, xs, tn, tg, act, sinp, t1, st;
     __bf16 *qk = nullptr, *vt = nullptr;
@@ -307,7 +308,7 @@ static int ensure_workspace(f5hip_dit* m, int rows_pad, int frames, int n_seq) {
         a.reset(pass ? (char*)m->ws.ptr : nullptr);
         m->h = a.f32(R * D); m->h0 = a.f32(R * D); m->ce = a.f32(R * D); m->pred = a.f32(R * 128);
         m->te = a.f32(R * Td); m->ty = a.f32(R * 2 * Td); m->gx = a.f32(S * 2 * Td);
-        m->mod = a.f32((size_t)128 * m->n_adaln + 64); m->xstate = a.f32(U * c.mel_dim); m->temb = a.f32((size_t)128 * D);
+        m->mod = a.f32((size_t)128 * m->n_adaln + 64); m->xstate = a.f32(U * c.mel_dim); m->xmid = a.f32(U * c.mel_dim); m->temb = a.f32((size_t)128 * D);
         m->hn = a.plane2(R * D + 256); m->c1 = a.plane2(R * D + 256); m->ao = a.plane2(R * D); m->ff = a.plane2(R * F);
         m->xs = a.plane2(R * 128); m->tn = a.plane2(R * Td); m->tg = a.plane2(R * 2 * Td); m->act = a.plane2(R * (128 + m->td_pad));
         m->sinp = a.plane2(128 * 256); m->t1 = a.plane2((size_t)128 * D); m->st = a.plane2((size_t)128 * D);
@@ -830,6 +831,13 @@ int f5hip_cfm_sample(f5hip_dit* m, int32_t n_utt, const int32_t* dur, const floa
     return f5hip_cfm_sample_masked(m, n_utt, dur, nullptr, cond_dev, cond_mask, text, nt_max, y0_dev, t_grid, steps, cfg_strength, out_dev, stream);
 }
 
+int f5hip_dit_set_ode_method(f5hip_dit* m, int32_t method) {
+    if (!m) return fail(-1, "null model");
+    if (method != 0 && method != 1) return fail(-1, "ode method %d: 0 = euler, 1 = midpoint", method);
+    m->ode_method = method;
+    return 0;
+}
+
 int f5hip_cfm_sample_masked(f5hip_dit* m, int32_t n_utt, const int32_t* dur, const int32_t* kv_len, const float* cond_dev, const uint8_t* cond_mask,
                             const int32_t* text, int32_t nt_max, const float* y0_dev, const float* t_grid, int32_t steps,
                             float cfg_strength, float* out_dev, void* stream) {
@@ -861,14 +869,41 @@ int f5hip_cfm_sample_masked(f5hip_dit* m, int32_t n_utt, const int32_t* dur, con
     hipLaunchKernelGGL(split_rows_kernel, dim3(M), dim3(256), 0, st, m->xstate, mel, mel, M, m->d_row_frame, m->xs.hi, m->xs.lo, 128, 0);
     CKL("split x");
     CK(precompute_text_and_ce(m, cond_dev, st));
-    CK(precompute_time(m, t_grid, steps, st));
-    for (int i = 0; i < steps; i++) {
-        CK(forward_step(m, i, -1, st));
-        prof_begin(PROF_OTHER, st);
-        hipLaunchKernelGGL(cfg_euler_kernel, dim3(f0), dim3(128), 0, st, m->xstate, mel, f0, m->pred, 128, m->d_urow_c, m->d_urow_u,
-                           cfg_strength, t_grid[i + 1] - t_grid[i], m->xs.hi, m->xs.lo, 128);
-        prof_end(PROF_OTHER, st);
-        CKL("cfg_euler");
+    if (m->ode_method == 0) {
+        CK(precompute_time(m, t_grid, steps, st));
+        for (int i = 0; i < steps; i++) {
+            CK(forward_step(m, i, -1, st));
+            prof_begin(PROF_OTHER, st);
+            hipLaunchKernelGGL(cfg_euler_kernel, dim3(f0), dim3(128), 0, st, m->xstate, m->xstate, mel, f0, m->pred, 128, m->d_urow_c, m->d_urow_u,
+                               cfg_strength, t_grid[i + 1] - t_grid[i], m->xs.hi, m->xs.lo, 128);
+            prof_end(PROF_OTHER, st);
+            CKL("cfg_euler");
+        }
+    } else {
+        // explicit midpoint on the fixed grid (torchdiffeq method="midpoint"): time points 2i = t_i, 2i + 1 = t_i + dt_i / 2
+        if (2 * steps > 128) return fail(-8, "midpoint: at most 64 steps per call (got %d)", steps);
+        std::vector<float> t2((size_t)2 * steps);
+        for (int i = 0; i < steps; i++) {
+            const float half = 0.5f * (t_grid[i + 1] - t_grid[i]);
+            t2[2 * i] = t_grid[i];
+            t2[2 * i + 1] = t_grid[i] + half;
+        }
+        CK(precompute_time(m, t2.data(), 2 * steps, st));
+        for (int i = 0; i < steps; i++) {
+            const float dt = t_grid[i + 1] - t_grid[i];
+            CK(forward_step(m, 2 * i, -1, st));
+            prof_begin(PROF_OTHER, st);
+            hipLaunchKernelGGL(cfg_euler_kernel, dim3(f0), dim3(128), 0, st, m->xmid, m->xstate, mel, f0, m->pred, 128, m->d_urow_c, m->d_urow_u,
+                               cfg_strength, 0.5f * dt, m->xs.hi, m->xs.lo, 128);
+            prof_end(PROF_OTHER, st);
+            CKL("cfg_euler half");
+            CK(forward_step(m, 2 * i + 1, -1, st));
+            prof_begin(PROF_OTHER, st);
+            hipLaunchKernelGGL(cfg_euler_kernel, dim3(f0), dim3(128), 0, st, m->xstate, m->xstate, mel, f0, m->pred, 128, m->d_urow_c, m->d_urow_u,
+                               cfg_strength, dt, m->xs.hi, m->xs.lo, 128);
+            prof_end(PROF_OTHER, st);
+            CKL("cfg_euler full");
+        }
     }
     hipLaunchKernelGGL(final_select_kernel, dim3(f0), dim3(128), 0, st, m->xstate, cond_dev, m->d_frame_is_cond, mel, f0, out_dev);
     CKL("final_select");

@@ -209,6 +209,52 @@ def cross_fade_concat(waves, fade_seconds, sample_rate=target_sample_rate):
     return out
 
 
+class PreparedVoice:
+    """The per-voice part of `infer_process` done once: the reference wave after mono mix / rms gain / resampling
+    (F/infer/utils_infer.py:423-433), its measured rms, its duration in seconds before resampling (the `max_chars` rule, :379) and --
+    filled in by the first request that uses it -- the reference mel on the device (the "reference latents": 188 KB for a 5 s
+    prompt).  `serve.TTSManager` keeps one per voice; `infer_requests` accepts it wherever a `ref_audio` is expected."""
+
+    def __init__(self, ref_audio, target_rms=0.1, device=None):
+        wav, sr = ref_audio if isinstance(ref_audio, tuple) else load_wav(ref_audio)
+        self.seconds = wav.shape[-1] / sr
+        self.audio, self.rms = _prepare_reference(wav, sr, target_rms, device)
+        self.ref_frames = self.audio.shape[-1] // hop_length
+        self.mel = None
+
+    def cond(self, model_obj):
+        """What to hand the sampler as the prompt: the cached mel [1, n, mel] when the model object can compute one, else the wave."""
+        if not hasattr(model_obj, "cond_mel"):
+            return self.audio
+        if self.mel is None:
+            self.mel = model_obj.cond_mel(self.audio)
+        return self.mel
+
+
+def _plan_request(ref_audio, ref_text, gen_text_batches, target_rms, speed, fix_duration, device, tokenizer):
+    """Host prologue of infer_batch_process for one request (F/infer/utils_infer.py:423-454): prepared reference wave, its rms,
+    the frame count the reference strips afterwards, and one sampling unit per text chunk."""
+    voice = ref_audio if isinstance(ref_audio, PreparedVoice) else PreparedVoice(ref_audio, target_rms, device)
+    if len(ref_text[-1].encode("utf-8")) == 1:
+        ref_text = ref_text + " "
+    return voice, plan_units(ref_text, gen_text_batches, voice.ref_frames, speed, fix_duration, tokenizer)
+
+
+def _vocode_and_join(mels, ref_frames, rms, vocoder, mel_spec_type, target_rms, cross_fade_duration):
+    """Tail of infer_batch_process (F/infer/utils_infer.py:468-524): strip the reference frames, vocode, restore the rms, cross-fade."""
+    if mel_spec_type not in ("vocos", "bigvgan"):
+        raise ValueError(mel_spec_type)
+    waves, specs = [], []
+    for mel in mels:
+        spec = mel.to(torch.float32)[ref_frames:, :].t()[None]                     # [1, mel, T] (:468-470)
+        wave = vocoder.decode(spec) if mel_spec_type == "vocos" else vocoder(spec)
+        if rms < target_rms:
+            wave = wave * rms / target_rms
+        waves.append(wave.squeeze().cpu().numpy())
+        specs.append(spec[0].cpu().numpy())
+    return cross_fade_concat(waves, cross_fade_duration), target_sample_rate, np.concatenate(specs, axis=1)
+
+
 def infer_batch_process(ref_audio, ref_text, gen_text_batches, model_obj, vocoder, mel_spec_type="vocos", progress=None,
                         target_rms=0.1, cross_fade_duration=0.15, nfe_step=32, cfg_strength=2.0, sway_sampling_coef=-1,
                         speed=1, fix_duration=None, device=None, tokenizer=text_to_tokens):
@@ -218,24 +264,71 @@ def infer_batch_process(ref_audio, ref_text, gen_text_batches, model_obj, vocode
     units, so here they are planned first and sampled in ONE `sample_units()` call when the model object offers it (F5HipModel: all
     chunks packed back to back, each with the reference's batch-1 semantics, the reference-audio mel computed once instead of once
     per chunk); any other object with the reference's `.sample()` is driven chunk by chunk like the reference does."""
-    audio, rms = _prepare_reference(*ref_audio, target_rms, device)
-    if len(ref_text[-1].encode("utf-8")) == 1:
-        ref_text = ref_text + " "
-    ref_frames = audio.shape[-1] // hop_length
-    units = plan_units(ref_text, gen_text_batches, ref_frames, speed, fix_duration, tokenizer)
+    voice, units = _plan_request(ref_audio, ref_text, gen_text_batches, target_rms, speed, fix_duration, device, tokenizer)
     knobs = dict(steps=nfe_step, cfg_strength=cfg_strength, sway_sampling_coef=sway_sampling_coef)
     if hasattr(model_obj, "sample_units"):
-        mels = model_obj.sample_units(audio, units, **knobs)                       # list of [frames_i, mel] incl. the reference frames
+        mels = model_obj.sample_units(voice.cond(model_obj), units, **knobs)        # list of [frames_i, mel] incl. the reference frames
     else:
-        mels = [model_obj.sample(cond=audio, text=[tokens], duration=frames, **knobs)[0][0] for tokens, frames in units]
-    if mel_spec_type not in ("vocos", "bigvgan"):
-        raise ValueError(mel_spec_type)
-    waves, specs = [], []
-    for mel in mels:
-        spec = mel.to(torch.float32)[ref_frames:, :].t()[None]                     # strip the reference frames: [1, mel, T] (:468-470)
-        wave = vocoder.decode(spec) if mel_spec_type == "vocos" else vocoder(spec)
-        if rms < target_rms:
-            wave = wave * rms / target_rms
-        waves.append(wave.squeeze().cpu().numpy())
-        specs.append(spec[0].cpu().numpy())
-    return cross_fade_concat(waves, cross_fade_duration), target_sample_rate, np.concatenate(specs, axis=1)
+        mels = [model_obj.sample(cond=voice.audio, text=[tokens], duration=frames, **knobs)[0][0] for tokens, frames in units]
+    return _vocode_and_join(mels, voice.ref_frames, voice.rms, vocoder, mel_spec_type, target_rms, cross_fade_duration)
+
+
+def infer_requests(requests, model_obj, vocoder, mel_spec_type=mel_spec_type, target_rms=target_rms,
+                   cross_fade_duration=cross_fade_duration, nfe_step=nfe_step, cfg_strength=cfg_strength,
+                   sway_sampling_coef=sway_sampling_coef, speed=speed, fix_duration=fix_duration, device=None, tokenizer=text_to_tokens):
+    """Several `infer_process()` calls as ONE sampler batch: `requests` = [(ref_audio, ref_text, gen_text)], each with its own
+    reference voice (a path, a (wave, sr) pair or a `PreparedVoice`); returns one (wave, sample_rate, spectrogram) triple per request, each equal to what `infer_process` returns for
+    that request alone (units keep the reference's batch-1 semantics, so the batch composition does not leak; noise is drawn unit by
+    unit in request order, i.e. the draws of the sequential calls).  This is what the serving queue (`serve.MicroBatcher`) and the
+    multi-voice front-end hand to the GPU: the chunks of all waiting requests are packed back to back in one library call."""
+    plans, flat_units, flat_cond, flat_audio = [], [], [], []
+    for ref_audio, ref_text, gen_text in requests:
+        voice = ref_audio if isinstance(ref_audio, PreparedVoice) else PreparedVoice(ref_audio, target_rms, device)
+        max_chars = int(len(ref_text.encode("utf-8")) / voice.seconds * (25 - voice.seconds))                 # utils_infer.py:379
+        voice, units = _plan_request(voice, ref_text, chunk_text(gen_text, max_chars=max_chars), target_rms, speed, fix_duration, device, tokenizer)
+        plans.append((voice, len(units)))
+        flat_units += units
+        flat_cond += [voice.cond(model_obj)] * len(units)
+        flat_audio += [voice.audio] * len(units)
+    knobs = dict(steps=nfe_step, cfg_strength=cfg_strength, sway_sampling_coef=sway_sampling_coef)
+    if hasattr(model_obj, "sample_units"):
+        mels = model_obj.sample_units(flat_cond, flat_units, **knobs)
+    else:
+        mels = [model_obj.sample(cond=a, text=[tokens], duration=frames, **knobs)[0][0] for a, (tokens, frames) in zip(flat_audio, flat_units)]
+    out, k = [], 0
+    for voice, n in plans:
+        out.append(_vocode_and_join(mels[k:k + n], voice.ref_frames, voice.rms, vocoder, mel_spec_type, target_rms, cross_fade_duration))
+        k += n
+    return out
+
+
+_VOICE_TAG = re.compile(r"\[(\w+)\]")
+
+
+def split_voice_tags(text_gen, voices):
+    """Multi-voice script -> [(voice, text)] (F/infer/infer_cli.py:181-197): the text is cut in front of every `[tag]`; a piece without a
+    tag, or with a tag that is not in `voices`, is spoken by "main"; empty pieces are dropped; the tag itself is not spoken."""
+    pieces = []
+    for piece in re.split(r"(?=\[\w+\])", text_gen):
+        if not piece.strip():
+            continue
+        m = _VOICE_TAG.match(piece)
+        voice = m.group(1) if m and m.group(1) in voices else "main"
+        text = _VOICE_TAG.sub("", piece).strip()
+        if text:   # (a tag with nothing behind it would hand the reference an empty gen_text; dropped here)
+            pieces.append((voice, text))
+    return pieces
+
+
+def infer_multi_voice(text_gen, voices, model_obj, vocoder, **kw):
+    """The multi-voice loop of the reference's CLI (F/infer/infer_cli.py:181-208): `voices` = {"main": {"ref_audio": path | (wave, sr),
+    "ref_text": str}, "<tag>": {...}}; every `[tag]` piece is synthesized with its voice and the pieces are concatenated (no
+    cross-fade between voices, like the reference).  All pieces go to the GPU as ONE `infer_requests` batch instead of one
+    `infer_process` call after the other.  Returns (wave, sample_rate, [spectrogram per piece])."""
+    if "main" not in voices:
+        raise ValueError('voices needs a "main" entry')
+    pieces = split_voice_tags(text_gen, voices)
+    if not pieces:
+        raise ValueError("nothing to synthesize")
+    res = infer_requests([(voices[v]["ref_audio"], voices[v]["ref_text"], t) for v, t in pieces], model_obj, vocoder, **kw)
+    return np.concatenate([w for w, _, _ in res]), target_sample_rate, [s for _, _, s in res]

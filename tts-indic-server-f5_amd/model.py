@@ -69,7 +69,13 @@ def _ptr(t):
 
 class F5HipModel:
     def __init__(self, arch: DiTArch | UNetTArch, state_dict: dict, vocab_char_map: dict | None = None, gemm_planes: int = 3,
-                 device: str | torch.device = "cuda:0", mel_spec_type: str = "vocos"):
+                 device: str | torch.device = "cuda:0", mel_spec_type: str = "vocos", odeint_kwargs: dict | None = None):
+        # odeint_kwargs: CFM's constructor argument (F/model/cfm.py:37-41), dict(method="euler") by default; "midpoint" is the other
+        # fixed-grid solver the reference names.  Adaptive torchdiffeq solvers are not offered.
+        self.odeint_kwargs = dict(odeint_kwargs) if odeint_kwargs is not None else dict(method="euler")
+        method = self.odeint_kwargs.get("method", "euler")
+        if method not in ("euler", "midpoint") or set(self.odeint_kwargs) - {"method"}:
+            raise ValueError(f"odeint_kwargs={self.odeint_kwargs!r}: only method='euler' or 'midpoint' on the fixed grid is supported")
         self.arch = arch
         self.device = torch.device(device)
         self.vocab_char_map = vocab_char_map
@@ -93,6 +99,7 @@ class F5HipModel:
             a = np.ascontiguousarray(v.detach().to(torch.float32).cpu().numpy())
             _lib.check(self._lib.f5hip_dit_load_param(self._h, k.encode(), _ptr(a), a.size), "load_param " + k)
         _lib.check(self._lib.f5hip_dit_finalize(self._h), "f5hip_dit_finalize")
+        _lib.check(self._lib.f5hip_dit_set_ode_method(self._h, 1 if method == "midpoint" else 0), "f5hip_dit_set_ode_method")
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
@@ -140,14 +147,27 @@ class F5HipModel:
 
     @torch.no_grad()
     def sample_units(self, audio, units, *, steps=32, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=None):
-        """All text chunks of one request in ONE sampler call (they are independent `sample()` calls in the reference,
-        F/infer/utils_infer.py:441-466).  `audio` [1, nw] reference wave (or its mel [1, n, mel]); `units` = [(tokens, frames)].
-        Returns one [frames_i, mel] tensor per unit.  Noise is drawn unit by unit in order, i.e. the same draws the reference's
-        sequential calls make from the global generator."""
-        cond = self.cond_mel(audio) if audio.ndim == 2 else audio.to(self.device, torch.float32)
+        """Independent sampling units in ONE sampler call: the text chunks of one request (independent `sample()` calls in the
+        reference, F/infer/utils_infer.py:441-466), or the chunks of several requests with different voices (`infer.infer_requests`).
+        `audio`: the reference wave [1, nw] (or its mel [1, n, mel]) shared by all units, or a list with one such tensor per unit;
+        `units` = [(tokens, frames)].  Returns one [frames_i, mel] tensor per unit.  Every unit keeps batch-1 semantics with its own
+        prompt length (`lens`), and noise is drawn unit by unit in order, i.e. the same draws the reference's sequential calls make
+        from the global generator."""
         b = len(units)
         frames = torch.tensor([int(f) for _, f in units], dtype=torch.long)
-        out, _ = self.sample(cond.expand(b, -1, -1), [t for t, _ in units], frames, steps=steps, cfg_strength=cfg_strength,
+        lens = None
+        if isinstance(audio, (list, tuple)):
+            assert len(audio) == b, "one reference per unit"
+            mels, cache = [], {}
+            for a in audio:   # the mel of a voice is computed once however many units share it
+                if id(a) not in cache:
+                    cache[id(a)] = (self.cond_mel(a) if a.ndim == 2 else a.to(self.device, torch.float32))[0]
+                mels.append(cache[id(a)])
+            lens = torch.tensor([m.shape[0] for m in mels], dtype=torch.long)
+            cond = torch.nn.utils.rnn.pad_sequence(mels, batch_first=True)
+        else:
+            cond = (self.cond_mel(audio) if audio.ndim == 2 else audio.to(self.device, torch.float32)).expand(b, -1, -1)
+        out, _ = self.sample(cond, [t for t, _ in units], frames, lens=lens, steps=steps, cfg_strength=cfg_strength,
                              sway_sampling_coef=sway_sampling_coef, seed=seed)
         # (sample() raises a duration to lens + 1 like the reference does, cfm.py:136: the rows of unit i are its FINAL duration)
         return [out[i, :self._last_min_frames[i]] for i in range(b)]

@@ -11,11 +11,19 @@ Differences, explicit:
     from GitHub on every request (`tts_utils.py:40-46`), which this deployment target (no egress) cannot and should not do;
   * the response body is 16-bit PCM WAV at 24 kHz written with the stdlib (`soundfile`'s default WAV subtype for float input
     is PCM_16 as well);
-  * `TTSManager.load()` takes the model / vocoder objects (or a loader callable): checkpoints are not fetched from the hub.
+  * `TTSManager.load()` takes the model / vocoder objects (or a loader callable): checkpoints are not fetched from the hub;
+  * `TTSManager(micro_batch=dict(max_requests=16, max_wait_ms=5))`: concurrent requests are collected for a few milliseconds and synthesized as ONE
+    sampler batch (`infer.infer_requests`); with `ShardedSampler` as the model object that batch is dealt over the GPUs of the node
+    (rank 0 serves HTTP and owns the queue, the other ranks sit in `rank_worker_loop`).  The reference serves one request at a
+    time on one GPU (`S/routes/speech.py:19-41`); results per request are the same.
 """
 
 import io
+import queue
+import threading
+import time
 import wave as _wave
+from concurrent.futures import Future
 from dataclasses import dataclass, field
 from typing import Callable
 
@@ -43,18 +51,91 @@ class VoiceRegistry:
         return self.voices.get(name)
 
 
+class MicroBatcher:
+    """Collects concurrent synthesis requests into one sampler batch.
+
+    `submit((ref_audio, ref_text, gen_text))` returns a `concurrent.futures.Future`; a single worker thread takes the first waiting
+    request, keeps collecting for at most `max_wait_ms` or until `max_requests` are waiting, runs `run_batch(list_of_requests)` (one
+    `infer.infer_requests` call = one library call over all chunks of all requests) and resolves the futures in order.  One batch is in
+    flight at a time -- the library allows one call per handle -- and the next one forms while it runs, so under load the batch size
+    grows by itself.  A failing batch is retried request by request so one bad request cannot fail its neighbours."""
+
+    def __init__(self, run_batch: Callable[[list], list], max_requests: int = 16, max_wait_ms: float = 5.0):
+        self.run_batch, self.max_requests, self.max_wait = run_batch, int(max_requests), max_wait_ms / 1e3
+        self._q: queue.Queue = queue.Queue()
+        self._stop = threading.Event()
+        self.batch_sizes: list[int] = []          # observability: sizes of the batches run so far
+        self._thread = threading.Thread(target=self._loop, name="f5hip-microbatcher", daemon=True)
+        self._thread.start()
+
+    def submit(self, request) -> Future:
+        if self._stop.is_set():
+            raise RuntimeError("MicroBatcher is closed")
+        f: Future = Future()
+        self._q.put((request, f))
+        return f
+
+    def close(self):
+        self._stop.set()
+        self._q.put(None)
+        self._thread.join(timeout=30)
+
+    def _collect(self):
+        first = self._q.get()
+        if first is None:
+            return None
+        batch, deadline = [first], time.monotonic() + self.max_wait
+        while len(batch) < self.max_requests:
+            left = deadline - time.monotonic()
+            try:
+                item = self._q.get(timeout=left) if left > 0 else self._q.get_nowait()
+            except queue.Empty:
+                break
+            if item is None:
+                self._q.put(None)   # leave the shutdown mark for the loop
+                break
+            batch.append(item)
+        return batch
+
+    def _loop(self):
+        while not self._stop.is_set():
+            batch = self._collect()
+            if batch is None:
+                break
+            self.batch_sizes.append(len(batch))
+            try:
+                results = self.run_batch([r for r, _ in batch])
+                if len(results) != len(batch):
+                    raise RuntimeError(f"run_batch returned {len(results)} results for {len(batch)} requests")
+                for (_, f), res in zip(batch, results):
+                    f.set_result(res)
+            except Exception as e:   # noqa: BLE001 -- isolate the failing request
+                if len(batch) == 1:
+                    batch[0][1].set_exception(e)
+                    continue
+                for r, f in batch:
+                    try:
+                        f.set_result(self.run_batch([r])[0])
+                    except Exception as e1:   # noqa: BLE001
+                        f.set_exception(e1)
+
+
 class TTSManager:
     """`S/core/managers.py:62-85`.  `model` is what `synthesize` calls: (text, ref_audio_path=..., ref_text=...) -> waveform."""
 
     def __init__(self, loader: Callable[[], tuple] | None = None, nfe_step: int = infer.nfe_step, cfg_strength: float = infer.cfg_strength,
-                 sway_sampling_coef: float = infer.sway_sampling_coef, speed: float = infer.speed, mel_spec_type: str = "vocos"):
+                 sway_sampling_coef: float = infer.sway_sampling_coef, speed: float = infer.speed, mel_spec_type: str = "vocos",
+                 micro_batch: dict | None = None):
         self.loader = loader
+        self.micro_batch = micro_batch            # e.g. dict(max_requests=16, max_wait_ms=5): batch concurrent requests
+        self.batcher: MicroBatcher | None = None
         self.model = None
         self.model_obj = None
         self.vocoder = None
         self.opts = dict(nfe_step=nfe_step, cfg_strength=cfg_strength, sway_sampling_coef=sway_sampling_coef, speed=speed)
         self.mel_spec_type = mel_spec_type
-        self._prep_cache: dict = {}   # prompt path -> (processed wav path, ref_text): the pre-step runs once per voice
+        self._prep_cache: dict = {}   # prompt path -> (PreparedVoice, ref_text): clip / trim / resample / mel run once per voice
+        self._prep_lock = threading.Lock()   # route handlers run in a thread pool: concurrent first requests of a voice prepare it once
 
     def load(self, model_obj=None, vocoder=None):
         """Attach the sampler / vocoder objects (F5HipModel, F5HipVocos | F5HipBigVGAN), or build them with `loader`."""
@@ -65,16 +146,29 @@ class TTSManager:
                 model_obj, vocoder = self.loader()
             self.model_obj, self.vocoder = model_obj, vocoder
             self.model = self._call
+            if self.micro_batch is not None:
+                self.batcher = MicroBatcher(self._run_batch, **self.micro_batch)
         return self
 
-    def _call(self, text, ref_audio_path, ref_text):
+    def _run_batch(self, requests):
+        res = infer.infer_requests(requests, self.model_obj, self.vocoder, mel_spec_type=self.mel_spec_type, **self.opts)
+        return [np.asarray(w, dtype=np.float32) for w, _, _ in res]
+
+    def _voice(self, ref_audio_path, ref_text):
+        """Once per voice: the reference's pre-step (clip to 15 s / trim silence, `preprocess_ref_audio_text`), then the prologue of
+        every `infer_process` call for it (mono, rms gain, 24 kHz) and -- on first use -- its mel on the device."""
         key = (ref_audio_path, ref_text)
-        if key not in self._prep_cache:
-            self._prep_cache[key] = infer.preprocess_ref_audio_text(ref_audio_path, ref_text, show_info=lambda *_: None)
-        wav_path, ref_text_n = self._prep_cache[key]
-        wave, _, _ = infer.infer_process(wav_path, ref_text_n, text, self.model_obj, self.vocoder, mel_spec_type=self.mel_spec_type,
-                                         show_info=lambda *_: None, **self.opts)
-        return np.asarray(wave, dtype=np.float32)
+        with self._prep_lock:
+            if key not in self._prep_cache:
+                wav_path, ref_text_n = infer.preprocess_ref_audio_text(ref_audio_path, ref_text, show_info=lambda *_: None)
+                self._prep_cache[key] = (infer.PreparedVoice(wav_path), ref_text_n)
+            return self._prep_cache[key]
+
+    def _call(self, text, ref_audio_path, ref_text):
+        voice, ref_text_n = self._voice(ref_audio_path, ref_text)
+        if self.batcher is not None:   # wait for the batch this request rides in (the route runs in a worker thread, see create_app)
+            return self.batcher.submit((voice, ref_text_n, text)).result()
+        return self._run_batch([(voice, ref_text_n, text)])[0]
 
     def synthesize(self, text, ref_audio_path, ref_text):
         if not self.model:
@@ -144,14 +238,111 @@ def create_app(tts_manager: TTSManager, registry: VoiceRegistry):
             raise HTTPException(status_code=e.status_code, detail=e.detail)
         return StreamingResponse(buf, media_type="audio/wav", headers={"Content-Disposition": f"attachment; filename={filename}"})
 
+    # The reference's handlers are `async def` around a blocking call, i.e. one request at a time.  Here the blocking part runs in
+    # starlette's thread pool, so concurrent requests overlap and meet in the MicroBatcher queue (when the manager has one).
+    from starlette.concurrency import run_in_threadpool
+
     @router.post("/audio/speech", response_class=StreamingResponse)
     async def synthesize_kannada(request: KannadaSynthesizeRequest):
-        return _run(request.text, registry.default_voice, None, "synthesized_kannada_speech.wav")
+        return await run_in_threadpool(_run, request.text, registry.default_voice, None, "synthesized_kannada_speech.wav")
 
     @router.post("/audio/speech/voice", response_class=StreamingResponse)
     async def synthesize_with_voice(request: SynthesizeRequest):     # the generic form the reference's helper already supports
-        return _run(request.text, request.ref_audio_name, request.ref_text, "synthesized_speech.wav")
+        return await run_in_threadpool(_run, request.text, request.ref_audio_name, request.ref_text, "synthesized_speech.wav")
 
     app = FastAPI(title="F5-TTS on MI355X (HIP path)")
     app.include_router(router)
     return app
+
+
+# ---------------------------------------------------------------------------------------------------------------- multi-GPU backend
+class ShardedSampler:
+    """The model object of rank 0 in a one-process-per-GPU serving job: `sample_units` deals the units of a batch over the ranks
+    (`sharding.shard_units`: longest-processing-time dealing with the SURVEY 8(d) cost model), every rank -- this one included --
+    samples its share on its own GPU with its own replica of the weights, and the mels come back to rank 0 in unit order.
+    There is no collective inside the ODE loop: one job broadcast (tokens, frame counts, the reference mels of the voices in the
+    batch: 188 KB per voice) and one gather per batch, RCCL over xGMI when the process group's backend is "nccl".
+    Ranks > 0 run `rank_worker_loop(local_model)`; `close()` on rank 0 releases them."""
+
+    def __init__(self, local_model, device=None):
+        import torch
+        import torch.distributed as dist
+        self.local, self.dist, self.torch = local_model, dist, torch
+        self.device = device if device is not None else getattr(local_model, "device", torch.device("cpu"))
+        self.vocab_char_map = getattr(local_model, "vocab_char_map", None)
+
+    # what infer.* needs from a model object
+    def cond_mel(self, audio):
+        return self.local.cond_mel(audio)
+
+    def sample_units(self, audio, units, **knobs):
+        torch = self.torch
+        b = len(units)
+        audios = list(audio) if isinstance(audio, (list, tuple)) else [audio] * b
+        voices, voice_of = [], []
+        for a in audios:                                   # distinct voices of the batch, by object identity
+            for k, v in enumerate(voices):
+                if v is a:
+                    voice_of.append(k)
+                    break
+            else:
+                voices.append(a)
+                voice_of.append(len(voices) - 1)
+        mels = [(self.local.cond_mel(a) if a.ndim == 2 else a)[0].to(torch.float32) for a in voices]
+        job = dict(units=[(list(t), int(f)) for t, f in units], voice_of=voice_of, mel_shapes=[tuple(m.shape) for m in mels], knobs=knobs)
+        return _run_sharded_job(self.local, job, mels, self.device)
+
+    def close(self):
+        if self.dist.is_initialized() and self.dist.get_world_size() > 1:
+            self.dist.broadcast_object_list([None], src=0)
+
+
+def _run_sharded_job(local_model, job, mels, device):
+    """Collective part shared by rank 0 (`job`, `mels` given) and the workers (both None): returns the mels of all units on rank 0."""
+    import torch
+    import torch.distributed as dist
+    from .sharding import gather_waves, shard_units
+    multi = dist.is_initialized() and dist.get_world_size() > 1
+    rank, world = (dist.get_rank(), dist.get_world_size()) if multi else (0, 1)
+    if multi:
+        box = [job]
+        dist.broadcast_object_list(box, src=0)
+        job = box[0]
+        if job is None:
+            return None
+        flat = torch.cat([m.reshape(-1) for m in mels]).to(device) if rank == 0 else torch.empty(sum(a * b for a, b in job["mel_shapes"]), device=device)
+        dist.broadcast(flat, src=0)
+        mels, k = [], 0
+        for a, b in job["mel_shapes"]:
+            mels.append(flat[k:k + a * b].view(a, b))
+            k += a * b
+    units = job["units"]
+    mine = shard_units([f for _, f in units], world)[rank]
+    outs = local_model.sample_units([mels[job["voice_of"][i]][None] for i in mine], [units[i] for i in mine], **job["knobs"]) if mine else []
+    # payload of a rank: the row count of each of its units, then their rows (a unit's final duration can exceed the planned frames:
+    # sample() raises it to lens + 1 like the reference, cfm.py:136)
+    mel_dim = mels[0].shape[1]
+    counts = torch.tensor([float(o.shape[0]) for o in outs], dtype=torch.float32, device=device)
+    packed = torch.cat([counts] + [o.reshape(-1).to(device, torch.float32) for o in outs])
+    got = gather_waves(packed, dst=0)
+    if rank != 0:
+        return []
+    result = [None] * len(units)
+    shards = shard_units([f for _, f in units], world)
+    for r, flat_r in enumerate(got):
+        k = len(shards[r])
+        for j, i in enumerate(shards[r]):
+            n = int(flat_r[j])
+            result[i] = flat_r[k:k + n * mel_dim].view(n, mel_dim)
+            k += n * mel_dim
+    return result
+
+
+def rank_worker_loop(local_model, device=None):
+    """What ranks > 0 of a serving job run: take part in every job rank 0's `ShardedSampler` broadcasts until it closes."""
+    import torch
+    device = device if device is not None else getattr(local_model, "device", torch.device("cpu"))
+    n = 0
+    while _run_sharded_job(local_model, None, None, device) is not None:
+        n += 1
+    return n
