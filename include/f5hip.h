@@ -134,6 +134,16 @@ int f5hip_op_attention(int32_t n_seq, const int32_t* seq_len, const int32_t* kv_
  *   rms = 1: x-transformers RMSNorm y = x / max(|x|_2, 1e-12) * sqrt(D) * scale.  All fp32 [M][D] / [D]. */
 int f5hip_op_layernorm(int32_t M, int32_t D, const float* x_dev, const float* scale_dev, const float* shift_dev, float gain_off, float eps,
                        int32_t rms, float* out_dev, void* stream);
+/* f5hip_op_conv1d: one nn.Conv1d(c_in, c_out, k, dilation = dil, padding = dil (k - 1) / 2) + bias + res of the BigVGAN generator (its
+ *   AMPBlock1 convolutions: k 3 / 7 / 11, dilation 1 / 3 / 5) over channel-last rows: `batch` sequences of pitch P rows (P % 128 == 0), T valid,
+ *   zero padding at the sequence bounds.  x_dev fp32 [batch P][c_in], w_host [c_out][c_in][k] (the module's weight layout), bias_host [c_out]
+ *   or NULL, res_dev fp32 [batch P][c_out] or NULL, out_dev fp32 [batch P][c_out] (rows >= T of a sequence are unspecified).
+ *   prec 2 = split bf16, 3 = one fp16 plane.  impl 0 = implicit GEMM (gemm.h), 5 = sliding-window kernel (conv5.h; fails if it does not
+ *   cover the shape).  iters > 0: average microseconds per launch in *avg_us.  stamps_host (optional, impl 5): [stamp_blocks][16] cycle
+ *   stamps of a diagnostics launch (layout: csrc/conv5.h). */
+int f5hip_op_conv1d(int32_t batch, int32_t P, int32_t T, int32_t c_in, int32_t c_out, int32_t k, int32_t dil, const float* x_dev,
+                    const float* w_host, const float* bias_host, const float* res_dev, float* out_dev, int32_t prec, int32_t impl,
+                    int32_t iters, double* avg_us, uint64_t* stamps_host, int32_t stamp_blocks, void* stream);
 
 /* ---------------------------------------------------------------- Vocos vocoder ----------------------- */
 

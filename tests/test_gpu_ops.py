@@ -206,3 +206,44 @@ def test_attention_unit_op(impl, lens, kv, heads):
     assert torch.isfinite(out).all()
     assert (out.double().cpu() - ref).abs().max().item() < 2e-2
     assert _rel(out, ref) < 4e-3
+
+
+# ---------------------------------------------------------------------------------------------------------------- conv1d (BigVGAN convolutions)
+def _conv_ref(x, w, bias, res, batch, P, T, dil):
+    """nn.Conv1d on the valid rows of every sequence (zero padding at the sequence bounds), channel-last in / out."""
+    M, ci = x.shape
+    k = w.shape[-1]
+    xv = x.view(batch, P, ci)[:, :T].transpose(1, 2).double()
+    y = torch.nn.functional.conv1d(xv, w.double(), None if bias is None else bias.double(), dilation=dil, padding=dil * (k - 1) // 2)
+    y = y.transpose(1, 2)
+    if res is not None:
+        y = y + res.view(batch, P, -1)[:, :T].double()
+    return y
+
+
+@pytest.mark.parametrize("impl", [5, 0])
+@pytest.mark.parametrize("prec,tol", [(2, 4e-5), (3, 4e-3)])
+@pytest.mark.parametrize("ci,co,k,dil,batch,P,T", [
+    (768, 768, 11, 5, 2, 512, 470),     # stage-1 shape, the largest halo (25 rows), 12 channel chunks of 64 / 24 of 32, 6 column tiles
+    (192, 192, 3, 1, 3, 256, 256),      # no padding rows at all: the window must stop at the sequence bounds, not read the neighbour
+    (96, 96, 7, 3, 2, 512, 300),        # 96 channels: 64-byte rows in fp16 mode (not a multiple of 64), one column tile of 128 with 96 real
+    (24, 24, 11, 1, 2, 1024, 1000),     # last stage: one chunk (no window double buffer), 24 of 64 columns real
+    (48, 48, 3, 5, 1, 512, 512),        # one chunk of 64 with 48 real channels
+    (384, 768, 3, 1, 2, 256, 200),      # c_out != c_in (the 3-tap form of an up-sampler)
+])
+def test_conv1d_vs_torch(impl, prec, tol, ci, co, k, dil, batch, P, T):
+    """f5hip_op_conv1d through both kernels (conv5.h sliding window, gemm.h implicit GEMM) vs torch conv1d in float64.
+    Tolerance (absolute, outputs of rms ~1.7): split bf16 carries ~16 mantissa bits per operand -- 2.4e-5 measured at K = 8448,
+    i.e. 1.4e-5 relative; fp16 (11 bits) is the documented fast mode."""
+    from tts_indic_server_f5_amd import ops
+    g = torch.Generator().manual_seed(1000 + ci + k + dil)
+    x = torch.randn(batch * P, ci, generator=g)
+    w = torch.randn(co, ci, k, generator=g) / (ci * k) ** 0.5
+    bias = torch.randn(co, generator=g)
+    res = torch.randn(batch * P, co, generator=g)
+    out, _, _ = ops.conv1d(x.to(DEV), w, bias, res.to(DEV), batch=batch, valid=T, dilation=dil, prec=prec, impl=impl)
+    ref = _conv_ref(x, w, bias, res, batch, P, T, dil)
+    got = out.cpu().view(batch, P, co)[:, :T].double()
+    err = (got - ref).abs().max().item()
+    print(f"[parity] conv1d impl {impl} prec {prec} ci {ci} co {co} k {k} dil {dil}: max err {err:.3e} (ref rms {ref.pow(2).mean().sqrt():.3f})")
+    assert err < tol

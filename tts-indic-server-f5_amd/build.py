@@ -16,8 +16,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(CSRC, "libf5hip.so")
-UNITS = ["f5hip.hip", "tu_gemm_reg.hip", "tu_gemm3.hip", "tu_gemm5_generic.hip", "tu_gemm5_qkv.hip", "tu_attn.hip"]
-HOT = ("gemm", "attn", "ln_kernel")   # kernels that must not touch scratch memory
+UNITS = ["f5hip.hip", "tu_gemm_reg.hip", "tu_gemm3.hip", "tu_gemm5_generic.hip", "tu_gemm5_qkv.hip", "tu_conv5.hip", "tu_attn.hip"]
+HOT = ("gemm", "conv5", "attn", "ln_kernel")   # kernels that must not touch scratch memory
 
 _INC = re.compile(r'^\s*#\s*include\s+"([^"]+)"', re.M)
 

@@ -386,6 +386,15 @@ static int bv_conv(f5hip_bigvgan* v, const BvConv& c, const Plane2& A, int M, in
     g.conv_kpt = c.c_in_pad / 32; g.conv_center = (c.k - 1) / 2; g.conv_dil = c.dil; g.conv_group_cols = 0;
     g.row_seq_start = nullptr; g.row_seq_end = nullptr; g.seq_pitch = P; g.seq_valid = T;
     g.act = act; g.res = res; g.ldres = ldo; g.out_f32 = out; g.ldo = ldo;
+    // conv5.h (window of the tile once in LDS, taps served from it) where it covers the shape; F5HIP_CONV5=0 keeps everything on gemm.h (A/B)
+    static const int use_conv5 = getenv("F5HIP_CONV5") ? atoi(getenv("F5HIP_CONV5")) : 1;
+    if (use_conv5 && v->nsplit >= 2) {
+        prof_begin(PROF_GEMM, st);
+        const hipError_t e = f5_launch_conv5(v->nsplit, g, c.w.n_pad, st);
+        prof_end(PROF_GEMM, st);
+        if (e == hipSuccess) { g_counters[4]++; return 0; }
+        if (e != hipErrorInvalidValue) return fail(-7, "conv5 launch: %s", hipGetErrorString(e));
+    }
     return run_gemm_n(v->nsplit, M, g, c.w, EPI_GENERIC, true, c.w.n_pad % 128 ? 64 : 128, st);
 }
 

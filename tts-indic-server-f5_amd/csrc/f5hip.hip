@@ -402,7 +402,7 @@ static GemmArgs gemm_base(const Plane2& A, int lda, const PackedW& W, int M) {
 }
 
 static int g_gemm_impl = -1;   // F5HIP_GEMM_IMPL: 0 = automatic; 1 = register-staged kernel only (gemm.h); 3 = gemm3 instead of gemm5 (A/B); 2 / 4 = experiments build only
-static long long g_counters[4] = {0, 0, 0, 0};   // f5hip_get_counter: gemm5 launches with RB 11 / RB 8 / 1 x 4 consumer layout / gemm3 wide-tile launches
+static long long g_counters[5] = {0, 0, 0, 0, 0};   // f5hip_get_counter: gemm5 launches with RB 11 / RB 8 / 1 x 4 consumer layout / gemm3 wide-tile launches
 
 // Kernel choice per GEMM (measured: profiles/r02_fillrate_microbench.txt, profiles/r01_gemm_microbench.txt, tools/gemm_microbench.py):
 //   fp16 one-plane operands with K % 64 == 0 (the four transformer-block GEMMs of the DiT in mixed mode): gemm5, exact-fit tiles;
@@ -490,10 +490,10 @@ static int run_ln(const LnArgs& a, hipStream_t st) {
 
 // Diagnostics for tests: which GEMM path the launches since the last reset took ("gemm5_rb11", "gemm5_rb8", "gemm5_wide", "gemm3_wide"); name "reset" zeroes them.
 extern "C" int f5hip_get_counter(const char* name, int64_t* value) {
-    static const char* names[4] = {"gemm5_rb11", "gemm5_rb8", "gemm5_wide", "gemm3_wide"};
+    static const char* names[5] = {"gemm5_rb11", "gemm5_rb8", "gemm5_wide", "gemm3_wide", "conv5"};
     if (!name) return fail(-1, "get_counter: null name");
     if (!strcmp(name, "reset")) { for (auto& c : g_counters) c = 0; return 0; }
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < 5; i++)
         if (!strcmp(name, names[i])) { if (value) *value = g_counters[i]; return 0; }
     return fail(-1, "unknown counter %s", name);
 }

@@ -267,3 +267,70 @@ extern "C" int f5hip_op_attention(int32_t n_seq, const int32_t* seq_len, const i
     if (hipStreamSynchronize(st) != hipSuccess) return fail(-7, "op_attention: %s", hipGetErrorString(hipGetLastError()));
     return 0;
 }
+
+
+// One Conv1d of the BigVGAN kind over channel-last rows -- batch sequences of pitch P rows, T valid -- through the library's two paths:
+// impl 0 = gemm.h implicit GEMM (A window re-read per tap), 5 = conv5.h (window once in LDS).  x_dev fp32 [batch * P][c_in],
+// w_host [c_out][c_in][k], out_dev fp32 [batch * P][c_out] (= conv + bias + res).  prec 2 = split bf16, 3 = fp16.
+// stamps_host (optional, impl 5, wide shapes): [blocks][16] cycle stamps of the diagnostics kernel (conv5.h).
+extern "C" int f5hip_op_conv1d(int32_t batch, int32_t P, int32_t T, int32_t c_in, int32_t c_out, int32_t k, int32_t dil, const float* x_dev,
+                               const float* w_host, const float* bias_host, const float* res_dev, float* out_dev, int32_t prec, int32_t impl,
+                               int32_t iters, double* avg_us, uint64_t* stamps_host, int32_t stamp_blocks, void* stream) {
+    if (batch <= 0 || P <= 0 || T <= 0 || T > P || P % 128 || c_in <= 0 || c_in % 4 || c_out <= 0 || k < 1 || !(k & 1) || dil < 1 || !x_dev || !w_host || !out_dev ||
+        (prec != 2 && prec != 3) || (impl != 0 && impl != 5))
+        return fail(-1, "op_conv1d: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    const int M = batch * P, cpad = ceil_to(c_in, 32);
+    BvConv c;
+    const std::vector<float> w(w_host, w_host + (size_t)c_out * c_in * k);
+    std::vector<float> bias(c_out, 0.0f);
+    if (bias_host) bias.assign(bias_host, bias_host + c_out);
+    if (bv_pack_conv(c, w, bias.data(), c_out, c_in, k, dil, prec == 3)) return -4;
+    OpBufs b;
+    Plane2 A;
+    A.hi = b.get<__bf16>((size_t)M * cpad + 4096); A.lo = b.get<__bf16>((size_t)M * cpad + 4096);
+    unsigned long long* stamps = stamps_host ? b.get<unsigned long long>((size_t)stamp_blocks * 16) : nullptr;
+    if (!A.hi || !A.lo || (stamps_host && !stamps)) { bv_free_conv(c); return fail(-5, "op_conv1d: hipMalloc"); }
+    (void)hipMemsetAsync(A.hi, 0, ((size_t)M * cpad + 4096) * 2, st);
+    (void)hipMemsetAsync(A.lo, 0, ((size_t)M * cpad + 4096) * 2, st);
+    const size_t n4 = (size_t)M * c_in / 4;
+    hipLaunchKernelGGL(bv_mean3_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, x_dev, x_dev, x_dev, 1, (size_t)M, c_in, (float*)nullptr, A.hi, A.lo, cpad,
+                       prec == 3 ? 2 : 1);
+    auto run = [&](float* out, const float* res, unsigned long long* stm) -> int {
+        GemmArgs g = gemm_base(A, c.c_in_pad, c.w, M);
+        g.conv_kpt = c.c_in_pad / 32; g.conv_center = (k - 1) / 2; g.conv_dil = dil; g.seq_pitch = P; g.seq_valid = T;
+        g.res = res; g.ldres = c_out; g.out_f32 = out; g.ldo = c_out; g.stamps = stm;
+        if (impl == 5) {
+            const hipError_t e = f5_launch_conv5(prec, g, c.w.n_pad, st);
+            if (e != hipSuccess) return fail(-7, "op_conv1d: conv5 %s", e == hipErrorInvalidValue ? "does not cover this shape" : hipGetErrorString(e));
+            return 0;
+        }
+        return run_gemm_n(prec, M, g, c.w, EPI_GENERIC, true, c.w.n_pad % 128 ? 64 : 128, st);
+    };
+    int rc = run(out_dev, res_dev, nullptr);
+    if (!rc && iters > 0 && avg_us) {
+        float* scratch = b.get<float>((size_t)M * c_out);
+        if (!scratch) rc = fail(-5, "op_conv1d: hipMalloc scratch");
+        hipEvent_t e0, e1;
+        (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+        for (int it = -3; it < iters && !rc; it++) {
+            if (it == 0) (void)hipEventRecord(e0, st);
+            rc = run(scratch, nullptr, nullptr);
+        }
+        (void)hipEventRecord(e1, st);
+        (void)hipEventSynchronize(e1);
+        float ms = 0.0f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        *avg_us = 1e3 * ms / iters;
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        if (!rc && stamps) {
+            (void)hipMemsetAsync(stamps, 0, (size_t)stamp_blocks * 16 * 8, st);
+            rc = run(scratch, nullptr, stamps);
+            if (!rc && (hipMemcpyAsync(stamps_host, stamps, (size_t)stamp_blocks * 16 * 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess))
+                rc = fail(-6, "op_conv1d: stamp download");
+        }
+    }
+    if (hipStreamSynchronize(st) != hipSuccess && !rc) rc = fail(-6, "op_conv1d: sync");
+    bv_free_conv(c);
+    return rc;
+}

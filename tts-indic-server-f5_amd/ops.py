@@ -75,3 +75,24 @@ def attention(q, k, v, seq_len, kv_len=None, *, heads, impl=3, iters=0):
     _lib.check(_lib.lib().f5hip_op_attention(len(sl), _p(sl), _p(kl), heads, _p(q), _p(k), _p(v), _p(out), impl, iters, C.byref(us),
                                              _lib.current_stream_ptr()), "f5hip_op_attention")
     return out, us.value
+
+
+def conv1d(x, weight, bias=None, res=None, *, batch, valid, dilation=1, prec=2, impl=5, iters=0, stamps=False):
+    """One BigVGAN-style Conv1d over channel-last rows.  x fp32 [batch * P, c_in] (P = rows per sequence, a multiple of 128; `valid`
+    rows of each are real, the rest is padding), weight [c_out, c_in, k] (nn.Conv1d layout), `same` zero padding at the sequence bounds.
+    Returns (out [batch * P, c_out], avg_us, stamps | None); impl 0 = implicit GEMM, 5 = sliding-window kernel."""
+    dev = x.device
+    x = _f32(x, dev)
+    c_out, c_in, k = weight.shape
+    M = x.shape[0]
+    P = M // batch
+    w = np.ascontiguousarray(weight.detach().to(torch.float32).cpu().numpy())
+    b = None if bias is None else np.ascontiguousarray(bias.detach().to(torch.float32).cpu().numpy())
+    r = None if res is None else _f32(res, dev)
+    out = torch.empty(M, c_out, dtype=torch.float32, device=dev)
+    us = C.c_double(0.0)
+    nblk = (M // 256) * ((c_out + 127) // 128)
+    st = np.zeros((nblk, 16), dtype=np.uint64) if stamps else None
+    _lib.check(_lib.lib().f5hip_op_conv1d(batch, P, valid, c_in, c_out, k, dilation, _p(x), _p(w), _p(b), _p(r), _p(out), prec, impl, iters,
+                                          C.byref(us), _p(st), nblk, _lib.current_stream_ptr()), "f5hip_op_conv1d")
+    return out, us.value, st
