@@ -29,8 +29,9 @@ typedef struct f5hip_dit_config {
     int32_t dim, depth, heads, ff_mult, text_dim, conv_layers, mel_dim, text_num_embeds;
     int32_t gemm_planes; /* GEMM operand precision, all with fp32 accumulation:
                             2 = split-bf16 "bf16x3" everywhere (strictest: 1.1e-4 mel RMS vs the fp32 reference at C2);
-                            3 = mixed (DiT): fp16 operands for the transformer-block GEMMs (QKV, out, FF1, FF2), bf16x3 for
-                                every GEMM that touches the ODE state / embeddings (3.1e-4 mel RMS, inside the 1e-3 bound);
+                            3 = mixed: fp16 operands for the transformer-block GEMMs (QKV, out, FF1, FF2), bf16x3 for every GEMM that
+                                touches the ODE state / embeddings / U-skips (3.1e-4 mel RMS for F5-Base at 32 NFE, 4.9e-4 for E2-Base
+                                at 64 NFE, against the reference's own CFM.sample outputs: inside the 1e-3 bound);
                             1 = plain bf16 (fast, ~8e-3 mel RMS: outside the bound) */
     int32_t arch;        /* 0 = DiT (F5-TTS, F/model/backbones/dit.py), 1 = UNetT (E2-TTS, F/model/backbones/unett.py: text_dim = mel_dim, conv_layers = 0) */
 } f5hip_dit_config;

@@ -38,7 +38,7 @@ struct f5hip_dit {
 #ifdef F5HIP_EXPERIMENTS
     StreamKWs sk;         // stream-K partial-tile slots + flags (experiments/gemm4.h), owned by the handle: launches of one handle are stream-ordered
 #endif
-    bool blk_f16 = false; // gemm_planes == 3: transformer-block GEMMs (QKV, out, FF1, FF2) take one fp16 plane per operand (DiT)
+    bool blk_f16 = false; // gemm_planes == 3: transformer-block GEMMs (QKV, out, FF1, FF2) take one fp16 plane per operand
     std::map<std::string, std::vector<float>> host;
     bool finalized = false;
     // packed weights
@@ -89,7 +89,9 @@ f5hip_dit* f5hip_dit_create(const f5hip_dit_config* cfg) {
     f5hip_dit* m = new f5hip_dit();
     m->cfg = *cfg;
     m->nsplit = cfg->gemm_planes == 3 ? 2 : cfg->gemm_planes;
-    m->blk_f16 = cfg->gemm_planes == 3 && cfg->arch == 0;
+    // both backbones: against the reference's own digests mixed mode measures 3.1e-4 rms (F5-Base, 32 NFE) and 4.9e-4 (E2-Base, N = 2340,
+    // 64 NFE) of the 1e-3 bound; the U-skip projections, the final norm + proj_out and the input embedding stay split bf16
+    m->blk_f16 = cfg->gemm_planes == 3;
     m->arch = cfg->arch;
     m->td_pad = ceil_to(cfg->text_dim, 32);
     m->gw = cfg->dim / 16;
@@ -645,6 +647,7 @@ static int forward_unett_layers(f5hip_dit* m, int ti, int n_blocks, hipStream_t 
             CK(run_gemm(m, sp, m->wskip[l], EPI_GENERIC, false, 64, st));
         }
         ln.scale = m->g_attn[l];
+        ln.f16_out = m->blk_f16 ? 1 : 0;   // block norms feed the fp16 block GEMMs in mixed mode; the final norm (proj_out) stays split bf16
         CK(run_ln(ln, st));
         GemmArgs q = gemm_base(m->hn, D, m->wqkv[l], M);
         q.D = D; q.row_pos = m->d_row_pos; q.rope_cos = m->rope_cos; q.rope_sin = m->rope_sin; q.qk = m->qk; q.vt = m->vt; q.ldvt = m->M_pad;
@@ -657,7 +660,7 @@ static int forward_unett_layers(f5hip_dit* m, int ti, int n_blocks, hipStream_t 
         ln.scale = m->g_ff[l];
         CK(run_ln(ln, st));
         GemmArgs f1 = gemm_base(m->hn, D, m->wff1[l], M);
-        f1.act = ACT_GELU_TANH; f1.out_hi = m->ff.hi; f1.out_lo = m->ff.lo; f1.ldob = F;
+        f1.act = ACT_GELU_TANH; f1.out_hi = m->ff.hi; f1.out_lo = m->ff.lo; f1.ldob = F; f1.f16_out = m->blk_f16 ? 1 : 0;
         CK(run_gemm(m, f1, m->wff1[l], EPI_GENERIC, false, 128, st));
         GemmArgs f2 = gemm_base(m->ff, F, m->wff2[l], M);
         f2.res = m->h; f2.ldres = D; f2.out_f32 = m->h; f2.ldo = D;
@@ -665,6 +668,7 @@ static int forward_unett_layers(f5hip_dit* m, int ti, int n_blocks, hipStream_t 
     }
     if (n_blocks >= 0) return 0;
     ln.scale = m->g_out;
+    ln.f16_out = 0;
     CK(run_ln(ln, st));
     GemmArgs po = gemm_base(m->hn, D, m->proj_out, M);
     po.out_f32 = m->pred; po.ldo = 128;
