@@ -4,90 +4,11 @@
 #pragma once
 #include "common.h"
 
-// ------------------------------------------------------------------------------------------------
-// LayerNorm over the last dim (biased variance, eps inside the sqrt, like torch), then
-//   y = n * (gain_off + scale[c]) + shift[c]
-// AdaLN-Zero: gain_off = 1, scale/shift from the modulation vector (F/model/modules.py:289,568,310);
-// affine LayerNorm: gain_off = 0, scale = weight, shift = bias (ConvNeXt blocks).
-// With dw_w != null the row is first replaced by a depthwise Conv1d(k=7, pad=3) over the frame axis
-// (zero padding at the sequence bounds): F/model/modules.py:262 / vocos ConvNeXtBlock.
-struct LnArgs {
-    const float* x; int ldx; int M; int D;
-    const float* scale; const float* shift; float gain_off; float eps;
-    const float* dw_w; const float* dw_b; const int* row_seq_start; const int* row_seq_end;
-    __bf16* out_hi; __bf16* out_lo; int ldo;
-    float* out_f32; int ldof;
-    int f16_out;   // 1: out_hi receives one fp16 plane (input of a PREC_F16 GEMM), out_lo unused
-    int rms;   // 1: x-transformers RMSNorm, y = x / max(||x||_2, 1e-12) * sqrt(D) * scale[c]  (no mean subtraction)
-};
+#include "ln_row.h"
 
 template <int NV>
 __global__ __launch_bounds__(256) void ln_kernel(const LnArgs p) {
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= p.M) return;
-    float4 v[NV];
-    float sum = 0.0f;
-#pragma unroll
-    for (int i = 0; i < NV; i++) {
-        const int c = (i * 64 + lane) * 4;
-        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (c < p.D) {
-            if (p.dw_w) {
-                const int s0 = p.row_seq_start[row], s1 = p.row_seq_end[row];
-                float4 a = *reinterpret_cast<const float4*>(p.dw_b + c);
-#pragma unroll
-                for (int k = 0; k < 7; k++) {
-                    const int r = row + k - 3;
-                    if (r >= s0 && r < s1) {
-                        const float4 xv = *reinterpret_cast<const float4*>(p.x + (size_t)r * p.ldx + c);
-                        a.x += p.dw_w[(c + 0) * 7 + k] * xv.x;
-                        a.y += p.dw_w[(c + 1) * 7 + k] * xv.y;
-                        a.z += p.dw_w[(c + 2) * 7 + k] * xv.z;
-                        a.w += p.dw_w[(c + 3) * 7 + k] * xv.w;
-                    }
-                }
-                v[i] = a;
-            } else {
-                v[i] = *reinterpret_cast<const float4*>(p.x + (size_t)row * p.ldx + c);
-            }
-            sum += v[i].x + v[i].y + v[i].z + v[i].w;
-        }
-    }
-    const float mean = p.rms ? 0.0f : wave_sum(sum) / (float)p.D;
-    float sq = 0.0f;
-#pragma unroll
-    for (int i = 0; i < NV; i++) {
-        const int c = (i * 64 + lane) * 4;
-        if (c < p.D) {
-            const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
-            sq += a * a + b * b + cc * cc + d * d;
-        }
-    }
-    const float sqt = wave_sum(sq);
-    const float rstd = p.rms ? sqrtf((float)p.D) / fmaxf(sqrtf(sqt), 1e-12f) : rsqrtf(sqt / (float)p.D + p.eps);
-#pragma unroll
-    for (int i = 0; i < NV; i++) {
-        const int c = (i * 64 + lane) * 4;
-        if (c < p.D) {
-            const float4 sc = *reinterpret_cast<const float4*>(p.scale + c);
-            const float4 sh = *reinterpret_cast<const float4*>(p.shift + c);
-            float y[4];
-            y[0] = (v[i].x - mean) * rstd * (p.gain_off + sc.x) + sh.x;
-            y[1] = (v[i].y - mean) * rstd * (p.gain_off + sc.y) + sh.y;
-            y[2] = (v[i].z - mean) * rstd * (p.gain_off + sc.z) + sh.z;
-            y[3] = (v[i].w - mean) * rstd * (p.gain_off + sc.w) + sh.w;
-            if (p.out_f32) *reinterpret_cast<float4*>(p.out_f32 + (size_t)row * p.ldof + c) = make_float4(y[0], y[1], y[2], y[3]);
-            if (p.out_hi && p.f16_out) {
-                store_f16x4(p.out_hi + (size_t)row * p.ldo + c, y);
-            } else if (p.out_hi) {
-                bf16x4 hi, lo;
-                split_bf16x4(y, hi, lo);
-                *reinterpret_cast<bf16x4*>(p.out_hi + (size_t)row * p.ldo + c) = hi;
-                if (p.out_lo) *reinterpret_cast<bf16x4*>(p.out_lo + (size_t)row * p.ldo + c) = lo;
-            }
-        }
-    }
+    ln_row<NV>(p, blockIdx.x * 4 + (threadIdx.x >> 6), threadIdx.x & 63);
 }
 
 // ------------------------------------------------------------------------------------------------

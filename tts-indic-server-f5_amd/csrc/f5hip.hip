@@ -39,6 +39,11 @@ struct f5hip_dit {
     StreamKWs sk;         // stream-K partial-tile slots + flags (experiments/gemm4.h), owned by the handle: launches of one handle are stream-ordered
 #endif
     bool blk_f16 = false; // gemm_planes == 3: transformer-block GEMMs (QKV, out, FF1, FF2) take one fp16 plane per operand
+    // fused LayerNorm in front of the QKV / FF1 GEMMs (gemm5 LNF kernels): per-handle arrival counters and a host-visible time-out flag
+    unsigned* ln_sync = nullptr;   // [16] row slabs, monotonic
+    unsigned ln_epoch = 0;         // fused launches since the counters were zeroed (every one adds 16 arrivals to each of its slabs)
+    int ln_slabs = 0;              // row slabs of those launches: a launch with another count zeroes the counters first (stream-ordered)
+    int* ln_err = nullptr;         // host-mapped: a kernel sets it when its slab barrier timed out
     std::map<std::string, std::vector<float>> host;
     bool finalized = false;
     // packed weights
@@ -93,6 +98,14 @@ f5hip_dit* f5hip_dit_create(const f5hip_dit_config* cfg) {
     // 64 NFE) of the 1e-3 bound; the U-skip projections, the final norm + proj_out and the input embedding stay split bf16
     m->blk_f16 = cfg->gemm_planes == 3;
     m->arch = cfg->arch;
+    if (hipMalloc((void**)&m->ln_sync, 16 * sizeof(unsigned)) != hipSuccess || hipMemset(m->ln_sync, 0, 16 * sizeof(unsigned)) != hipSuccess ||
+        hipHostMalloc((void**)&m->ln_err, sizeof(int), hipHostMallocMapped) != hipSuccess) {
+        set_error("hipMalloc LayerNorm-fusion state");
+        dev_free(m->ln_sync);
+        delete m;
+        return nullptr;
+    }
+    *m->ln_err = 0;
     m->td_pad = ceil_to(cfg->text_dim, 32);
     m->gw = cfg->dim / 16;
     m->n_adaln = cfg->arch == 0 ? cfg->depth * 6 * cfg->dim + 2 * cfg->dim : 0;
@@ -112,6 +125,8 @@ void f5hip_dit_destroy(f5hip_dit* m) {
         free_packed(b.pw1); free_packed(b.pw2);
     }
     for (float* p : {m->text_emb, m->text_pos, m->rope_cos, m->rope_sin}) dev_free(p);
+    dev_free(m->ln_sync);
+    if (m->ln_err) (void)hipHostFree(m->ln_err);
     dev_free(m->ws.ptr);
 #ifdef F5HIP_EXPERIMENTS
     streamk_ws_free(m->sk);
@@ -404,7 +419,7 @@ static GemmArgs gemm_base(const Plane2& A, int lda, const PackedW& W, int M) {
 }
 
 static int g_gemm_impl = -1;   // F5HIP_GEMM_IMPL: 0 = automatic; 1 = register-staged kernel only (gemm.h); 3 = gemm3 instead of gemm5 (A/B); 2 / 4 = experiments build only
-static long long g_counters[5] = {0, 0, 0, 0, 0};   // f5hip_get_counter: gemm5 launches with RB 11 / RB 8 / 1 x 4 consumer layout / gemm3 wide-tile launches
+static long long g_counters[7] = {0, 0, 0, 0, 0, 0, 0};   // f5hip_get_counter: gemm5 launches with RB 11 / RB 8 / 1 x 4 consumer layout / gemm3 wide-tile launches
 
 // Kernel choice per GEMM (measured: profiles/r02_fillrate_microbench.txt, profiles/r01_gemm_microbench.txt, tools/gemm_microbench.py):
 //   fp16 one-plane operands with K % 64 == 0 (the four transformer-block GEMMs of the DiT in mixed mode): gemm5, exact-fit tiles;
@@ -490,12 +505,95 @@ static int run_ln(const LnArgs& a, hipStream_t st) {
     return 0;
 }
 
+// ---- LayerNorm fused behind a residual GEMM (EXPERIMENT, -DF5HIP_EXPERIMENTS builds with F5HIP_LN_FUSE=1) ------------------------------
+// Measured and not shipped (profiles/r02_ln_fusion.txt): bit-identical to the separate kernel, but the fused residual GEMM takes 31.2 us
+// against 18.8 us + 6.1 us for the GEMM and the stand-alone LayerNorm.  The in-kernel chain is five dependent L2 round trips of 1.5-2 us
+// (store acknowledgement -> arrival atomic -> poll -> row loads -> stores); a kernel boundary resolves the same dependency in ~2 us.
+#ifdef F5HIP_EXPERIMENTS
+// The slab barrier of the LNE kernels needs (a) every workgroup of the launch resident at once and (b) the 16 workgroups of a row slab on
+// ONE XCD (their only coherence point is that XCD's L2).  (b) holds under gemm5's tile order if the hardware deals workgroup b to XCD
+// b % 8: probed once per process with s_getreg XCC_ID.  F5HIP_LN_FUSE=0 turns the fusion off (A/B, and the fallback after a time-out).
+__global__ void xcc_probe_kernel(int* out) {
+    if (threadIdx.x == 0) {
+        unsigned id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
+        out[blockIdx.x] = (int)(id & 0xF);
+    }
+}
+static int g_ln_fuse = -1;   // -1 not probed, 0 off, 1 on
+static int g_num_cus = 0;
+static void ln_fuse_probe() {
+    if (g_ln_fuse >= 0) return;
+    g_ln_fuse = 0;
+    if (!getenv("F5HIP_LN_FUSE") || atoi(getenv("F5HIP_LN_FUSE")) != 1) return;   // opt-in
+    hipDeviceProp_t prop;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return;
+    g_num_cus = prop.multiProcessorCount;
+    const int nb = 512;
+    int* d = nullptr;
+    std::vector<int> h(nb, -1);
+    if (hipMalloc((void**)&d, nb * sizeof(int)) != hipSuccess) return;
+    hipLaunchKernelGGL(xcc_probe_kernel, dim3(nb), dim3(64), 0, 0, d);
+    const bool ok = hipGetLastError() == hipSuccess && hipMemcpy(h.data(), d, nb * sizeof(int), hipMemcpyDeviceToHost) == hipSuccess;
+    (void)hipFree(d);
+    if (!ok) return;
+    for (int b = 0; b < nb; b++)
+        if (h[b] != h[b & 7]) return;               // workgroups b and b % 8 on different XCDs: no fusion
+    for (int x = 1; x < 8; x++)
+        for (int y = 0; y < x; y++)
+            if (h[x] == h[y]) return;               // fewer than 8 XCDs in the round robin
+    g_ln_fuse = 1;
+}
+
+#endif
+
+// Residual GEMM g (out projection / FF2: updates the stream h in place) followed by the LayerNorm `ln` over h: one LNE kernel when the
+// launch is one resident wave of exact-fit tiles with 16 column tiles per slab and 8 or 16 slabs (a slab then sits on one XCD) AND the
+// library is an experiments build with F5HIP_LN_FUSE=1; otherwise -- the shipped path -- two launches.
+static int run_gemm_ln(f5hip_dit* m, GemmArgs& g, const PackedW& W, const LnArgs& ln, hipStream_t st) {
+#ifdef F5HIP_EXPERIMENTS
+    ln_fuse_probe();
+    if (g_ln_fuse == 1 && *m->ln_err) {             // a barrier of an earlier call timed out: its results were wrong; never again
+        g_ln_fuse = 0;
+        g_counters[6]++;
+        return fail(-9, "fused LayerNorm: a slab barrier timed out in an earlier launch (its output is invalid); the fusion is now off");
+    }
+    if (g_ln_fuse == 1 && W.f16 && !ln.dw_w && !ln.out_f32 && ln.D == 1024 && ln.ldx == 1024 && ln.x == g.out_f32 && g.ldo == 1024 && W.n == 1024 && g.K % 64 == 0 &&
+        g_gemm_impl == 0) {
+        const Gemm5Choice c5 = gemm5_choose(g.M, W.n_pad);
+        const int bm = c5.rb * 16, bnn = c5.cb * 16;
+        const int tiles_m = c5.rb ? (g.M + bm - 1) / bm : 0, tiles_n = c5.rb ? W.n_pad / bnn : 0;
+        if (c5.rb && c5.cb == 4 && tiles_n == 16 && (tiles_m == 8 || tiles_m == 16) && tiles_m * tiles_n <= g_num_cus) {
+            if (tiles_m != m->ln_slabs) {           // counters of slabs the earlier launches did not have would lag behind the epoch
+                if (hipMemsetAsync(m->ln_sync, 0, 16 * sizeof(unsigned), st) != hipSuccess) return fail(-6, "fused LayerNorm: counter reset");
+                m->ln_epoch = 0;
+                m->ln_slabs = tiles_m;
+            }
+            g.ln = ln;
+            g.ln_sync = m->ln_sync;
+            g.ln_target = ++m->ln_epoch * 16u;
+            g.ln_err = m->ln_err;
+            prof_begin(PROF_GEMM, st);
+            const hipError_t e = f5_launch_gemm5_generic_lne(g, c5.rb, c5.cb, W.n_pad, st);
+            prof_end(PROF_GEMM, st);
+            if (e != hipSuccess) return fail(-7, "gemm5 LNE launch: %s", hipGetErrorString(e));
+            g_counters[c5.rb == 11 ? 0 : 1]++;
+            g_counters[5]++;
+            return 0;
+        }
+    }
+#endif
+    if (const int r = run_gemm(m, g, W, EPI_GENERIC, false, 64, st)) return r;
+    return run_ln(ln, st);
+}
+
 // Diagnostics for tests: which GEMM path the launches since the last reset took ("gemm5_rb11", "gemm5_rb8", "gemm5_wide", "gemm3_wide"); name "reset" zeroes them.
 extern "C" int f5hip_get_counter(const char* name, int64_t* value) {
-    static const char* names[5] = {"gemm5_rb11", "gemm5_rb8", "gemm5_wide", "gemm3_wide", "conv5"};
+    static const char* names[7] = {"gemm5_rb11", "gemm5_rb8", "gemm5_wide", "gemm3_wide", "conv5", "ln_fused", "ln_fuse_timeouts"};
     if (!name) return fail(-1, "get_counter: null name");
     if (!strcmp(name, "reset")) { for (auto& c : g_counters) c = 0; return 0; }
-    for (int i = 0; i < 5; i++)
+    for (int i = 0; i < 7; i++)
         if (!strcmp(name, names[i])) { if (value) *value = g_counters[i]; return 0; }
     return fail(-1, "unknown counter %s", name);
 }
@@ -648,17 +746,16 @@ static int forward_unett_layers(f5hip_dit* m, int ti, int n_blocks, hipStream_t 
         }
         ln.scale = m->g_attn[l];
         ln.f16_out = m->blk_f16 ? 1 : 0;   // block norms feed the fp16 block GEMMs in mixed mode; the final norm (proj_out) stays split bf16
-        CK(run_ln(ln, st));
         GemmArgs q = gemm_base(m->hn, D, m->wqkv[l], M);
         q.D = D; q.row_pos = m->d_row_pos; q.rope_cos = m->rope_cos; q.rope_sin = m->rope_sin; q.qk = m->qk; q.vt = m->vt; q.ldvt = m->M_pad;
+        CK(run_ln(ln, st));
         CK(run_gemm(m, q, m->wqkv[l], EPI_QKV, false, 128, st));
         CK(launch_attention(m, st));
         GemmArgs o = gemm_base(m->ao, D, m->wout[l], M);
         o.res = m->h; o.ldres = D; o.out_f32 = m->h; o.ldo = D;
         o.row_keep = m->any_masked ? m->d_row_keep : nullptr;
-        CK(run_gemm(m, o, m->wout[l], EPI_GENERIC, false, 64, st));
         ln.scale = m->g_ff[l];
-        CK(run_ln(ln, st));
+        CK(run_gemm_ln(m, o, m->wout[l], ln, st));     // out projection + the feed-forward norm behind it
         GemmArgs f1 = gemm_base(m->hn, D, m->wff1[l], M);
         f1.act = ACT_GELU_TANH; f1.out_hi = m->ff.hi; f1.out_lo = m->ff.lo; f1.ldob = F; f1.f16_out = m->blk_f16 ? 1 : 0;
         CK(run_gemm(m, f1, m->wff1[l], EPI_GENERIC, false, 128, st));
@@ -741,12 +838,18 @@ static int forward_step(f5hip_dit* m, int ti, int n_blocks, hipStream_t st) {
 
     const int nb = n_blocks < 0 ? c.depth : n_blocks;
     if (m->arch == 1) return forward_unett_layers(m, ti, n_blocks, st);
+    // Every LayerNorm but the first is launched together with the residual GEMM in front of it (run_gemm_ln: one kernel where the launch
+    // is exact-fit): the out projection carries norm 2 of its block, FF2 carries norm 1 of the next block or the final norm.
+    const float* mf = mod + (size_t)c.depth * 6 * D;   // final (scale, shift): F/model/modules.py:308
+    auto block_ln = [&](const float* shift, const float* scale) {
+        LnArgs ln; memset(&ln, 0, sizeof(ln));
+        ln.x = m->h; ln.ldx = D; ln.M = M; ln.D = D; ln.shift = shift; ln.scale = scale; ln.gain_off = 1.0f; ln.eps = 1e-6f;
+        ln.out_hi = m->hn.hi; ln.out_lo = m->hn.lo; ln.ldo = D; ln.f16_out = m->blk_f16 ? 1 : 0;
+        return ln;
+    };
+    if (nb > 0) CK(run_ln(block_ln(mod, mod + D), st));
     for (int l = 0; l < nb; l++) {
         const float* ml = mod + (size_t)l * 6 * D;   // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
-        LnArgs ln; memset(&ln, 0, sizeof(ln));
-        ln.x = m->h; ln.ldx = D; ln.M = M; ln.D = D; ln.shift = ml; ln.scale = ml + D; ln.gain_off = 1.0f; ln.eps = 1e-6f;
-        ln.out_hi = m->hn.hi; ln.out_lo = m->hn.lo; ln.ldo = D; ln.f16_out = m->blk_f16 ? 1 : 0;
-        CK(run_ln(ln, st));
         GemmArgs q = gemm_base(m->hn, D, m->wqkv[l], M);
         q.D = D; q.row_pos = m->d_row_pos; q.rope_cos = m->rope_cos; q.rope_sin = m->rope_sin; q.qk = m->qk; q.vt = m->vt; q.ldvt = m->M_pad;
         CK(run_gemm(m, q, m->wqkv[l], EPI_QKV, false, 128, st));
@@ -756,22 +859,28 @@ static int forward_step(f5hip_dit* m, int ti, int n_blocks, hipStream_t st) {
         GemmArgs o = gemm_base(m->ao, D, m->wout[l], M);
         o.mul = ml + 2 * D; o.res = m->h; o.ldres = D; o.out_f32 = m->h; o.ldo = D;
         o.row_keep = m->any_masked ? m->d_row_keep : nullptr;
-        CK(run_gemm(m, o, m->wout[l], EPI_GENERIC, false, 64, st));
-        ln.shift = ml + 3 * D; ln.scale = ml + 4 * D;
-        CK(run_ln(ln, st));
+        CK(run_gemm_ln(m, o, m->wout[l], block_ln(ml + 3 * D, ml + 4 * D), st));
         GemmArgs f1 = gemm_base(m->hn, D, m->wff1[l], M);
         f1.act = ACT_GELU_TANH; f1.out_hi = m->ff.hi; f1.out_lo = m->ff.lo; f1.ldob = F; f1.f16_out = m->blk_f16 ? 1 : 0;
         CK(run_gemm(m, f1, m->wff1[l], EPI_GENERIC, false, 128, st));
         GemmArgs f2 = gemm_base(m->ff, F, m->wff2[l], M);
         f2.mul = ml + 5 * D; f2.res = m->h; f2.ldres = D; f2.out_f32 = m->h; f2.ldo = D;
-        CK(run_gemm(m, f2, m->wff2[l], EPI_GENERIC, false, 64, st));
+        if (l + 1 < nb) {
+            CK(run_gemm_ln(m, f2, m->wff2[l], block_ln(ml + 6 * D, ml + 7 * D), st));   // norm 1 of block l + 1
+        } else if (n_blocks < 0) {
+            LnArgs lf = block_ln(mf + D, mf);      // final norm: (scale, shift) order, split-bf16 planes for proj_out
+            lf.f16_out = 0;
+            CK(run_gemm_ln(m, f2, m->wff2[l], lf, st));
+        } else {
+            CK(run_gemm(m, f2, m->wff2[l], EPI_GENERIC, false, 64, st));
+        }
     }
     if (n_blocks >= 0) return 0;
-    const float* mf = mod + (size_t)c.depth * 6 * D;   // (scale, shift): F/model/modules.py:308
-    LnArgs ln; memset(&ln, 0, sizeof(ln));
-    ln.x = m->h; ln.ldx = D; ln.M = M; ln.D = D; ln.scale = mf; ln.shift = mf + D; ln.gain_off = 1.0f; ln.eps = 1e-6f;
-    ln.out_hi = m->hn.hi; ln.out_lo = m->hn.lo; ln.ldo = D;
-    CK(run_ln(ln, st));
+    if (nb == 0) {                                     // (a model without blocks: the final norm has no GEMM to ride on)
+        LnArgs lf = block_ln(mf + D, mf);
+        lf.f16_out = 0;
+        CK(run_ln(lf, st));
+    }
     GemmArgs po = gemm_base(m->hn, D, m->proj_out, M);
     po.out_f32 = m->pred; po.ldo = 128;
     CK(run_gemm(m, po, m->proj_out, EPI_GENERIC, false, 128, st));

@@ -361,7 +361,21 @@ F5_DEVICE void g5_v_rows(const GemmArgs& p, const float* slab, int m0, int n0, i
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
-template <bool F16, int EPI, int RB, int CB, int WR, int NST, int ABL = 0>
+// LNE (EXPERIMENT, instantiated in -DF5HIP_EXPERIMENTS builds only): the LayerNorm that FOLLOWS this residual GEMM (out projection -> norm 2, FF2 -> the next block's norm 1) fused behind its epilogue.
+// Only launched as ONE resident wave of workgroups (grid <= CUs, one workgroup per CU by its LDS size) with 16 column tiles per row slab:
+// when a slab's 16 workgroups have stored their tiles of the residual stream they meet at a slab-local barrier (an arrival counter in L2:
+// the XCD-blocked tile order puts them on one XCD -- probed at start-up, f5hip.hip), then workgroup j normalises rows j * BM / 16 ... of
+// the slab (one wave per row, ln_finish = the stand-alone kernel's arithmetic, so the bits are the same) and writes the operand plane
+// of the next GEMM.  The rows are read with agent-scope loads (this CU's L1 may still hold the tile's own residual columns from before
+// the update).  MEASURED AND NOT SHIPPED: bit-identical, but 31.2 us against 18.8 + 6.1 us for the two kernels it replaces (and the same
+// norm fused in FRONT of the following GEMM measured 2-5 % slower end to end): DESIGN.md section 6, profiles/r02_ln_fusion.txt.  The spin is bounded (~50 ms):
+// on a time-out the workgroup sets *p.ln_err and carries on (wrong results, no hang); the host then stops using these kernels.
+F5_DEVICE f32x4 g5_load_f4_agent(const float* ptr) {
+    f32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(ptr) : "memory");
+    return v;
+}
+template <bool F16, int EPI, int RB, int CB, int WR, int NST, int ABL = 0, bool LNE = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm5_kernel(const GemmArgs p, const int tiles_n, const int n_rows_w) {
     using C = Gemm5Cfg<RB, CB, NST>;
     constexpr int BM = C::BM, BN = C::BN, PIECES = C::PIECES, STAGE = C::STAGE;
@@ -468,6 +482,38 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         __syncthreads();                                           // E2
         g5_v_rows<RB, CB, NST>(p, slab, m0, n0, 0, wave, lane);
     }
+    if constexpr (LNE) {
+        static_assert(EPI == EPI_GENERIC && Gemm5Cfg<RB, CB, NST>::BM % 16 == 0, "16 workgroups share the rows of a slab of the residual stream");
+        constexpr int ROWS = Gemm5Cfg<RB, CB, NST>::BM / 16;       // rows this workgroup normalises (11 or 8)
+        static_assert(ROWS <= 16, "at most two rows per wave");
+        const int slab_i = tile / tiles_n, j = tile - slab_i * tiles_n;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's part of the tile is in L2 (write-through L1)
+        __syncthreads();
+        if (tid == 0) {
+            __hip_atomic_fetch_add(p.ln_sync + slab_i, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int spins = 0;
+            while ((int)(__hip_atomic_load(p.ln_sync + slab_i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - p.ln_target) < 0) {
+                if (++spins > (1 << 15)) { *p.ln_err = 1; break; }  // ~50 ms: the slab's other workgroups are not running
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        __syncthreads();
+        // rows wave and wave + 8 of this workgroup's share: every load (both rows, scale, shift) in flight before the first use
+        const int r0 = m0 + j * ROWS + wave, r1 = wave + 8 < ROWS ? r0 + 8 : p.ln.M;   // (r1 == M: no second row)
+        float4 v0[4], v1[4], sc[4], sh[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int c = (i * 64 + lane) * 4;
+            const f32x4 a = g5_load_f4_agent(p.ln.x + (size_t)min(r0, p.ln.M - 1) * p.ln.ldx + c);
+            const f32x4 b = g5_load_f4_agent(p.ln.x + (size_t)min(r1, p.ln.M - 1) * p.ln.ldx + c);
+            v0[i] = make_float4(a[0], a[1], a[2], a[3]);
+            v1[i] = make_float4(b[0], b[1], b[2], b[3]);
+        }
+        ln_load_mod<4>(p.ln, lane, sc, sh);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // (the asm loads are invisible to the compiler's own counting)
+        ln_finish<4>(p.ln, r0, lane, v0, sc, sh);
+        ln_finish<4>(p.ln, r1, lane, v1, sc, sh);
+    }
     G5_STAMP(4);
     if constexpr (ABL == 5) {
         if (p.stamps && (tid == 0 || tid == 256)) {
@@ -482,14 +528,24 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #undef G5_STAMP
 }
 
-template <bool F16, int EPI, int RB, int CB, int WR, int NST, int ABL = 0>
+template <bool F16, int EPI, int RB, int CB, int WR, int NST, int ABL = 0, bool LNE = false>
 static hipError_t launch_gemm5_t(const GemmArgs& a, int n_pad, hipStream_t st) {
     using C = Gemm5Cfg<RB, CB, NST>;
     static unsigned attr_mask = 0;
-    if (hipError_t e = f5_set_lds_attr(reinterpret_cast<const void*>(&gemm5_kernel<F16, EPI, RB, CB, WR, NST, ABL>), C::LDS, attr_mask); e != hipSuccess) return e;
+    if (hipError_t e = f5_set_lds_attr(reinterpret_cast<const void*>(&gemm5_kernel<F16, EPI, RB, CB, WR, NST, ABL, LNE>), C::LDS, attr_mask); e != hipSuccess) return e;
     const int tiles_m = (a.M + C::BM - 1) / C::BM, tiles_n = n_pad / C::BN;
-    hipLaunchKernelGGL((gemm5_kernel<F16, EPI, RB, CB, WR, NST, ABL>), dim3(tiles_m * tiles_n), dim3(512), C::LDS, st, a, tiles_n, n_pad);
+    if (LNE && (tiles_n != 16 || !a.ln_sync || !a.ln_err || a.ln.D != 1024 || a.ln.x != a.out_f32 || a.ln.dw_w)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((gemm5_kernel<F16, EPI, RB, CB, WR, NST, ABL, LNE>), dim3(tiles_m * tiles_n), dim3(512), C::LDS, st, a, tiles_n, n_pad);
     return hipGetLastError();
+}
+
+// residual GEMM + the LayerNorm behind it (out projection, FF2: generic epilogue, 64 columns = 16 column tiles of a 1024-wide stream)
+template <bool F16>
+static hipError_t launch_gemm5_lne(const GemmArgs& a, int rb, int cb, int n_pad, hipStream_t st) {
+    if (cb != 4) return hipErrorInvalidValue;
+    if (rb == 11) return launch_gemm5_t<F16, EPI_GENERIC, 11, 4, 4, 4, 0, true>(a, n_pad, st);
+    if (rb == 8) return launch_gemm5_t<F16, EPI_GENERIC, 8, 4, 4, 4, 0, true>(a, n_pad, st);
+    return hipErrorInvalidValue;
 }
 
 // (tile choice and the non-template entry points: gemm_launch.h / tu_gemm5_*.hip)

@@ -7,6 +7,7 @@
 // pairs of the QKV epilogue are lane-local.
 #pragma once
 #include "common.h"
+#include "ln_row.h"
 
 enum { EPI_GENERIC = 0, EPI_QKV = 1 };
 
@@ -64,6 +65,12 @@ struct GemmArgs {
     __bf16* qk;              // [M_pad][2 D]
     __bf16* vt;              // [D][ldvt]
     int ldvt;
+    // fused LayerNorm behind the epilogue (gemm5 LNE kernels): ln.x == out_f32 (the residual stream this GEMM updates); ln_sync[slab] counts
+    // the workgroups of a row slab that have stored their tile (monotonic: this launch waits for ln_target), *ln_err is set on a time-out
+    LnArgs ln;
+    unsigned* ln_sync;
+    unsigned ln_target;
+    int* ln_err;
     // diagnostics (ABL == 3 builds only)
     unsigned long long* stamps;
     int stamp_bx, stamp_by;

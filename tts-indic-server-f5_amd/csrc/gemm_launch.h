@@ -13,6 +13,10 @@ hipError_t f5_launch_gemm3(int prec, int epi, int bn, const GemmArgs& a, int m_p
 // gemm5.h: exact-fit (16 rb) x (16 cb) tiles, 64-deep k-steps, fp16 operands
 hipError_t f5_launch_gemm5_generic(const GemmArgs& a, int rb, int cb, int n_pad, hipStream_t st);
 hipError_t f5_launch_gemm5_qkv(const GemmArgs& a, int rb, int cb, int n_pad, hipStream_t st);
+// a residual GEMM (64-column tiles of a 1024-wide stream) with the LayerNorm that follows it fused behind the epilogue (GemmArgs::ln ...):
+// one resident wave of workgroups, 16 column tiles per row slab; hipErrorInvalidValue otherwise.  Experiments builds only (measured
+// slower than the two launches it replaces).
+hipError_t f5_launch_gemm5_generic_lne(const GemmArgs& a, int rb, int cb, int n_pad, hipStream_t st);
 // conv5.h: sliding-window Conv1d (the window of a 256-row tile once in LDS, taps served from it); hipErrorInvalidValue = shape not covered
 hipError_t f5_launch_conv5(int prec, const GemmArgs& a, int n_pad, hipStream_t st);
 // attn3.h: flash attention forward, 256 queries per workgroup
