@@ -365,3 +365,118 @@ def unett_forward(sd, cfg: UNetTConfig, x, cond, text, time, drop_audio_cond: bo
     assert not skips
     h = rms_norm(h, sd["transformer.norm_out.g"])[:, 1:, :]
     return F.linear(h, sd["transformer.proj_out.weight"], sd["transformer.proj_out.bias"])
+
+
+# ----------------------------------------------------------------------------
+# MMDiT backbone, F/model/backbones/mmdit.py:83-146 + MMDiTBlock / JointAttnProcessor (F/model/modules.py:578-642, 456-536)
+# ----------------------------------------------------------------------------
+
+@dataclass(frozen=True)
+class MMDiTConfig:
+    """MMDiT.__init__ arguments (mmdit.py:84-95): text is embedded at `dim`, no text ConvNeXt, the last block is context-pre-only."""
+    dim: int = 512
+    depth: int = 16
+    heads: int = 16
+    ff_mult: int = 2
+    text_num_embeds: int = 256
+    mel_dim: int = 100
+    dim_head: int = 64
+
+
+def mmdit_text_embed(sd, cfg: MMDiTConfig, text: torch.Tensor, drop_text: bool, p="transformer.text_embed.") -> torch.Tensor:
+    """TextEmbedding.forward, mmdit.py:37-52: ids + 1 (-1 padding -> filler 0), all ids 0 when dropped, + the absolute position table
+    precompute_freqs_cis(dim, 1024) at positions 0 .. nt - 1 (get_pos_embed_indices: clamped below max_pos).  The whole nt is kept."""
+    ids = text + 1
+    if drop_text:
+        ids = torch.zeros_like(ids)
+    e = F.embedding(ids, sd[p + "text_embed.weight"])
+    pos = torch.arange(ids.shape[1]).clamp(max=1023)
+    return e + text_pos_table(cfg.dim, end=1024)[pos][None]
+
+
+def mmdit_audio_embed(sd, x, cond, drop_audio_cond: bool, p="transformer.audio_embed.") -> torch.Tensor:
+    """AudioEmbedding.forward, mmdit.py:64-70: Linear(cat(x, cond)) + ConvPositionEmbedding (no mask) + residual."""
+    if drop_audio_cond:
+        cond = torch.zeros_like(cond)
+    h = F.linear(torch.cat((x, cond), dim=-1), sd[p + "linear.weight"], sd[p + "linear.bias"])
+    return conv_pos_embed(sd, p + "conv_pos_embed.", h) + h
+
+
+def joint_attention(sd, p: str, cfg: MMDiTConfig, x, c, mask, rope, c_rope, context_pre_only: bool):
+    """JointAttnProcessor.__call__, modules.py:460-536: separate projections for the audio stream x and the text stream c, rotary on each
+    with its OWN positions, softmax over the concatenated keys [x ; c] (padding mask on the x keys only), outputs split back."""
+    b, n, _ = x.shape
+    nt = c.shape[1]
+    q = apply_rotary(F.linear(x, sd[p + "to_q.weight"], sd[p + "to_q.bias"]), rope)
+    k = apply_rotary(F.linear(x, sd[p + "to_k.weight"], sd[p + "to_k.bias"]), rope)
+    v = F.linear(x, sd[p + "to_v.weight"], sd[p + "to_v.bias"])
+    qc = apply_rotary(F.linear(c, sd[p + "to_q_c.weight"], sd[p + "to_q_c.bias"]), c_rope)
+    kc = apply_rotary(F.linear(c, sd[p + "to_k_c.weight"], sd[p + "to_k_c.bias"]), c_rope)
+    vc = F.linear(c, sd[p + "to_v_c.weight"], sd[p + "to_v_c.bias"])
+    h, dh = cfg.heads, cfg.dim_head
+    Q = torch.cat([q, qc], dim=1).view(b, n + nt, h, dh).transpose(1, 2)
+    K = torch.cat([k, kc], dim=1).view(b, n + nt, h, dh).transpose(1, 2)
+    V = torch.cat([v, vc], dim=1).view(b, n + nt, h, dh).transpose(1, 2)
+    am = None
+    if mask is not None:
+        am = F.pad(mask, (0, nt), value=True)[:, None, None, :].expand(b, h, n + nt, n + nt)   # no mask for the text keys
+    o = F.scaled_dot_product_attention(Q, K, V, attn_mask=am, dropout_p=0.0, is_causal=False)
+    o = o.transpose(1, 2).reshape(b, n + nt, h * dh)
+    ox, oc = o[:, :n], o[:, n:]
+    ox = F.linear(ox, sd[p + "to_out.0.weight"], sd[p + "to_out.0.bias"])
+    if not context_pre_only:
+        oc = F.linear(oc, sd[p + "to_out_c.weight"], sd[p + "to_out_c.bias"])
+    if mask is not None:
+        ox = ox.masked_fill(~mask[..., None], 0.0)
+    return ox, oc
+
+
+def _ff(sd, p: str, h: torch.Tensor) -> torch.Tensor:
+    f = F.linear(h, sd[p + "ff.0.0.weight"], sd[p + "ff.0.0.bias"])
+    f = F.gelu(f, approximate="tanh")   # MMDiTBlock: FeedForward(approximate="tanh"), modules.py:607,612
+    return F.linear(f, sd[p + "ff.2.weight"], sd[p + "ff.2.bias"])
+
+
+def mmdit_block(sd, p: str, cfg: MMDiTConfig, x, c, t, mask, rope, c_rope, context_pre_only: bool):
+    """MMDiTBlock.forward, modules.py:614-642.  Returns (c, x); c is None behind the last (context-pre-only) block."""
+    d = cfg.dim
+    st = F.silu(t)
+    mc = F.linear(st, sd[p + "attn_norm_c.linear.weight"], sd[p + "attn_norm_c.linear.bias"])
+    if context_pre_only:
+        c_scale, c_shift = mc.chunk(2, dim=1)                     # AdaLayerNormZero_Final: (scale, shift), modules.py:308
+        norm_c = F.layer_norm(c, (d,), eps=1e-6) * (1 + c_scale[:, None]) + c_shift[:, None]
+    else:
+        c_shift_a, c_scale_a, c_gate_a, c_shift_m, c_scale_m, c_gate_m = mc.chunk(6, dim=1)
+        norm_c = F.layer_norm(c, (d,), eps=1e-6) * (1 + c_scale_a[:, None]) + c_shift_a[:, None]
+    mx = F.linear(st, sd[p + "attn_norm_x.linear.weight"], sd[p + "attn_norm_x.linear.bias"])
+    x_shift_a, x_scale_a, x_gate_a, x_shift_m, x_scale_m, x_gate_m = mx.chunk(6, dim=1)
+    norm_x = F.layer_norm(x, (d,), eps=1e-6) * (1 + x_scale_a[:, None]) + x_shift_a[:, None]
+    ax, ac = joint_attention(sd, p + "attn.", cfg, norm_x, norm_c, mask, rope, c_rope, context_pre_only)
+    if context_pre_only:
+        c = None
+    else:
+        c = c + c_gate_a[:, None] * ac
+        hc = F.layer_norm(c, (d,), eps=1e-6) * (1 + c_scale_m[:, None]) + c_shift_m[:, None]
+        c = c + c_gate_m[:, None] * _ff(sd, p + "ff_c.", hc)
+    x = x + x_gate_a[:, None] * ax
+    hx = F.layer_norm(x, (d,), eps=1e-6) * (1 + x_scale_m[:, None]) + x_shift_m[:, None]
+    x = x + x_gate_m[:, None] * _ff(sd, p + "ff_x.", hx)
+    return c, x
+
+
+def mmdit_forward(sd, cfg: MMDiTConfig, x, cond, text, time, drop_audio_cond: bool, drop_text: bool, mask=None) -> torch.Tensor:
+    """MMDiT.forward, mmdit.py:115-146."""
+    b, n = x.shape[:2]
+    if time.ndim == 0:
+        time = time.repeat(b)
+    t = time_embed(sd, time)
+    c = mmdit_text_embed(sd, cfg, text, drop_text)
+    h = mmdit_audio_embed(sd, x, cond, drop_audio_cond)
+    rope, c_rope = rotary_freqs(n, cfg.dim_head), rotary_freqs(text.shape[1], cfg.dim_head)
+    for i in range(cfg.depth):
+        c, h = mmdit_block(sd, f"transformer.transformer_blocks.{i}.", cfg, h, c, t, mask, rope, c_rope, i == cfg.depth - 1)
+    s = F.linear(F.silu(t), sd["transformer.norm_out.linear.weight"], sd["transformer.norm_out.linear.bias"])
+    scale, shift = s.chunk(2, dim=1)
+    h = F.layer_norm(h, (cfg.dim,), eps=1e-6) * (1 + scale)[:, None, :] + shift[:, None, :]
+    return F.linear(h, sd["transformer.proj_out.weight"], sd["transformer.proj_out.bias"])
+

@@ -222,6 +222,7 @@ def main():
     # ---- (4c) UNetT (E2-TTS): parameter order, tiny forward (b=1, both CFG branches), tiny CFM.sample, Small forward ----
     gen_unett_fixtures(cfm_mod, NoMel)
     gen_e2base_fixtures(cfm_mod, NoMel)
+    gen_mmdit_fixtures(cfm_mod, NoMel)
 
     # ---- (5) chunk_text / glue: reference's pure-python functions -----------------------
     gen_glue_fixtures()
@@ -302,6 +303,51 @@ def gen_e2base_fixtures(cfm_mod, NoMel, nfe_list=(8, 64)):
         print("e2-base sample", steps, "done", flush=True)
 
 
+MMTINY = dict(dim=128, depth=3, heads=2, ff_mult=2, text_num_embeds=40)
+
+
+def gen_mmdit_fixtures(cfm_mod, NoMel):
+    """The reference's own MMDiT (F/model/backbones/mmdit.py) on seeded synthetic weights: forward with both CFG branches at b = 1 and at
+    a padded b = 3 with mask (the joint-attention mask covers the audio keys only), the first block's two streams, and CFM.sample over
+    it (8 steps, CFG 2, sway -1).  depth 3 = two full dual-stream blocks + the context-pre-only last block."""
+    mm = importlib.import_module("f5_tts.model.backbones.mmdit")
+    sd = synth.mmdit_state_dict(**MMTINY)
+    net = mm.MMDiT(**MMTINY, mel_dim=100)
+    names = [n for n, _ in net.named_parameters()]
+    assert names == [k[len("transformer."):] for k in sd.keys()], "synth key order != reference MMDiT.named_parameters()"
+    net.load_state_dict({k[len("transformer."):]: v for k, v in sd.items()}, strict=True)
+    net = net.eval()
+    g = torch.Generator().manual_seed(31)
+    b, n, nt = 3, 50, 21
+    x = torch.randn(b, n, 100, generator=g)
+    cond = torch.randn(b, n, 100, generator=g) * (torch.arange(n)[None, :, None] < 17)
+    text = torch.randint(0, 40, (b, nt), generator=g)
+    text[1, 15:] = -1
+    text[2, 9:] = -1
+    tm = torch.tensor(0.37)
+    lens = torch.tensor([50, 41, 33])
+    mask = O.lens_to_mask(lens, n)
+    outs = {}
+    with torch.no_grad():
+        for tag, da, dt in (("cond", False, False), ("null", True, True)):
+            outs["out_b3_mask_" + tag] = net(x=x, cond=cond, text=text, time=tm, drop_audio_cond=da, drop_text=dt, mask=mask)
+            outs["out_b1_" + tag] = net(x=x[:1], cond=cond[:1], text=text[:1], time=tm, drop_audio_cond=da, drop_text=dt, mask=None)
+        t = net.time_embed(tm.repeat(1))
+        c0 = net.text_embed(text[:1], drop_text=False)
+        x0 = net.audio_embed(x[:1], cond[:1], drop_audio_cond=False)
+        rope, c_rope = net.rotary_embed.forward_from_seq_len(n), net.rotary_embed.forward_from_seq_len(nt)
+        c1, x1 = net.transformer_blocks[0](x0, c0, t, mask=None, rope=rope, c_rope=c_rope)
+        outs.update(text_embed=c0, audio_embed=x0, block0_c=c1, block0_x=x1)
+    cfm = cfm_mod.CFM(transformer=net, mel_spec_module=NoMel(), num_channels=100, odeint_kwargs=dict(method="euler")).eval()
+    gs = torch.Generator().manual_seed(32)
+    scond = torch.randn(1, 20, 100, generator=gs)
+    stext = torch.randint(0, 40, (1, 14), generator=gs)
+    sout, _ = cfm.sample(cond=scond, text=stext, duration=48, steps=8, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=7)
+    save("mmdit_tiny", x=x, cond=cond, text=text, time=tm, lens=lens, sample_cond=scond, sample_text=stext, sample_out=sout, **outs)
+    with open(os.path.join(HERE, "mmdit_param_order.json"), "w") as f:
+        json.dump(names, f)
+
+
 def gen_glue_fixtures():
     """infer/utils_infer.py needs torchaudio/pydub/vocos/matplotlib at import; give it empty stand-ins and use
     only its pure-python functions (chunk_text) and infer_batch_process's host glue with stub model/vocoder."""
@@ -375,6 +421,14 @@ if __name__ == "__main__":
             n_mel_channels = 100
 
         gen_unett_fixtures(importlib.import_module("f5_tts.model.cfm"), NoMel)
+    elif "--mmdit-only" in sys.argv:
+        install_leaf_shims()
+        importlib.import_module("f5_tts.model.modules")
+
+        class NoMel(torch.nn.Identity):
+            n_mel_channels = 100
+
+        gen_mmdit_fixtures(importlib.import_module("f5_tts.model.cfm"), NoMel)
     elif "--e2base-only" in sys.argv:
         torch.set_num_threads(8)
         install_leaf_shims()

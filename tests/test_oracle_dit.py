@@ -179,3 +179,36 @@ def test_rms_norm_scale():
     x = torch.randn(3, 5, 64)
     y = O.rms_norm(x, torch.ones(64))
     assert torch.allclose(y.pow(2).mean(-1), torch.ones(3, 5), atol=1e-5)   # unit RMS: ||y|| = sqrt(D)
+
+
+# ---- MMDiT (F/model/backbones/mmdit.py): the oracle vs the reference's own forward / CFM.sample on seeded weights ----
+
+MMTINY = dict(dim=128, depth=3, heads=2, ff_mult=2, text_num_embeds=40)
+
+
+def test_mmdit_param_order_matches_reference(golden_dir):
+    names = json.load(open(os.path.join(golden_dir, "mmdit_param_order.json")))
+    assert names == [k[len("transformer."):] for k in synth.mmdit_state_dict(**MMTINY).keys()]
+
+
+def test_mmdit_oracle_vs_reference_fixture(golden_dir):
+    g = _load(golden_dir, "mmdit_tiny")
+    sd, cfg = synth.mmdit_state_dict(**MMTINY), O.MMDiTConfig(**MMTINY)
+    mask = O.lens_to_mask(g["lens"], g["x"].shape[1])
+    for tag, da, dt in (("cond", False, False), ("null", True, True)):
+        o3 = O.mmdit_forward(sd, cfg, g["x"], g["cond"], g["text"], g["time"], da, dt, mask=mask)
+        _close(o3, g["out_b3_mask_" + tag], atol=3e-4, rtol=1e-4)
+        o1 = O.mmdit_forward(sd, cfg, g["x"][:1], g["cond"][:1], g["text"][:1], g["time"], da, dt)
+        _close(o1, g["out_b1_" + tag], atol=3e-4, rtol=1e-4)
+    c0 = O.mmdit_text_embed(sd, cfg, g["text"][:1], False)
+    x0 = O.mmdit_audio_embed(sd, g["x"][:1], g["cond"][:1], False)
+    _close(c0, g["text_embed"], atol=1e-5, rtol=1e-5)
+    _close(x0, g["audio_embed"], atol=1e-4, rtol=1e-4)
+    t = O.time_embed(sd, g["time"].repeat(1))
+    n, nt = g["x"].shape[1], g["text"].shape[1]
+    c1, x1 = O.mmdit_block(sd, "transformer.transformer_blocks.0.", cfg, x0, c0, t, None, O.rotary_freqs(n), O.rotary_freqs(nt), False)
+    _close(c1, g["block0_c"], atol=2e-4, rtol=1e-4)
+    _close(x1, g["block0_x"], atol=2e-4, rtol=1e-4)
+    out, _ = O.cfm_sample(sd, cfg, g["sample_cond"], g["sample_text"], 48, steps=8, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=7,
+                          forward_fn=lambda **kw: O.mmdit_forward(sd, cfg, **kw), keep_trajectory=False)
+    _close(out, g["sample_out"], atol=5e-4, rtol=1e-4)

@@ -87,6 +87,39 @@ def unett_param_specs(dim=1024, depth=24, heads=16, ff_mult=4, mel_dim=100, text
     return s
 
 
+def mmdit_param_specs(dim=512, depth=16, heads=16, ff_mult=2, mel_dim=100, text_num_embeds=256, dim_head=64):
+    """Ordered (name, shape, kind) list mirroring MMDiT.named_parameters() (F/model/backbones/mmdit.py:96-113, MMDiTBlock / Attention
+    F/model/modules.py:588-612, 335-390): the last block is context-pre-only (2 dim modulation for the text stream, no to_out_c, no ff_c)."""
+    inner = heads * dim_head
+    s = []
+    p = "transformer.time_embed.time_mlp."
+    s += [(p + "0.weight", (dim, 256), "linear"), (p + "0.bias", (dim,), "bias"),
+          (p + "2.weight", (dim, dim), "linear"), (p + "2.bias", (dim,), "bias")]
+    s += [("transformer.text_embed.text_embed.weight", (text_num_embeds + 1, dim), "embed")]
+    p = "transformer.audio_embed."
+    s += [(p + "linear.weight", (dim, mel_dim * 2), "linear"), (p + "linear.bias", (dim,), "bias")]
+    for j in (0, 2):
+        s += [(f"{p}conv_pos_embed.conv1d.{j}.weight", (dim, dim // 16, 31), "conv"),
+              (f"{p}conv_pos_embed.conv1d.{j}.bias", (dim,), "bias")]
+    for i in range(depth):
+        last = i == depth - 1
+        q = f"transformer.transformer_blocks.{i}."
+        s += [(q + "attn_norm_c.linear.weight", ((2 if last else 6) * dim, dim), "adaln"), (q + "attn_norm_c.linear.bias", ((2 if last else 6) * dim,), "adaln_bias"),
+              (q + "attn_norm_x.linear.weight", (6 * dim, dim), "adaln"), (q + "attn_norm_x.linear.bias", (6 * dim,), "adaln_bias")]
+        for nm in ("to_q", "to_k", "to_v", "to_k_c", "to_v_c", "to_q_c"):
+            s += [(f"{q}attn.{nm}.weight", (inner, dim), "linear"), (f"{q}attn.{nm}.bias", (inner,), "bias")]
+        s += [(q + "attn.to_out.0.weight", (dim, inner), "linear"), (q + "attn.to_out.0.bias", (dim,), "bias")]
+        if not last:
+            s += [(q + "attn.to_out_c.weight", (dim, inner), "linear"), (q + "attn.to_out_c.bias", (dim,), "bias")]
+            s += [(q + "ff_c.ff.0.0.weight", (dim * ff_mult, dim), "linear"), (q + "ff_c.ff.0.0.bias", (dim * ff_mult,), "bias"),
+                  (q + "ff_c.ff.2.weight", (dim, dim * ff_mult), "linear"), (q + "ff_c.ff.2.bias", (dim,), "bias")]
+        s += [(q + "ff_x.ff.0.0.weight", (dim * ff_mult, dim), "linear"), (q + "ff_x.ff.0.0.bias", (dim * ff_mult,), "bias"),
+              (q + "ff_x.ff.2.weight", (dim, dim * ff_mult), "linear"), (q + "ff_x.ff.2.bias", (dim,), "bias")]
+    s += [("transformer.norm_out.linear.weight", (2 * dim, dim), "adaln"), ("transformer.norm_out.linear.bias", (2 * dim,), "adaln_bias"),
+          ("transformer.proj_out.weight", (mel_dim, dim), "linear"), ("transformer.proj_out.bias", (mel_dim,), "bias")]
+    return s
+
+
 def vocos_param_specs(in_ch=100, dim=512, inter=1536, layers=8, n_fft=1024):
     """Ordered (name, shape, kind) list for vocos 0.1.0 `charactr/vocos-mel-24khz`."""
     s = [("backbone.embed.weight", (dim, in_ch, 7), "conv"), ("backbone.embed.bias", (dim,), "bias"),
@@ -174,6 +207,10 @@ def dit_state_dict(seed=SEED_DIT, **arch):
 
 def unett_state_dict(seed=SEED_DIT, **arch):
     return make_state_dict(unett_param_specs(**arch), seed)
+
+
+def mmdit_state_dict(seed=SEED_DIT, **arch):
+    return make_state_dict(mmdit_param_specs(**arch), seed)
 
 
 def vocos_state_dict(seed=SEED_VOCOS, **arch):
