@@ -131,6 +131,12 @@ int f5hip_op_qkv(int32_t M, int32_t D, const float* a_dev, const float* w_dev, c
  *   impl 3 = the production kernel (attn3); 4 = the experimental unequal-wave kernel (attn3 unless the library was built with experiments). */
 int f5hip_op_attention(int32_t n_seq, const int32_t* seq_len, const int32_t* kv_len, int32_t heads, const float* q_dev, const float* k_dev,
                        const float* v_dev, float* out_dev, int32_t impl, int32_t iters, double* avg_us, void* stream);
+/* f5hip_op_joint_attention: the joint attention of the MMDiT blocks (JointAttnProcessor, F/model/modules.py:496-522): per sequence the
+ *   queries and the keys are its audio rows followed by its text rows; only audio keys can be padding (x_kvlen[i] <= x_len[i] valid; NULL:
+ *   all).  q_dev / k_dev / v_dev / out_dev fp32 [sum(x_len) + sum(c_len)][64 heads]: all audio frames sequence by sequence, then all
+ *   text tokens sequence by sequence.  Operands are rounded to bf16 like the QKV epilogue's outputs. */
+int f5hip_op_joint_attention(int32_t n_seq, const int32_t* x_len, const int32_t* x_kvlen, const int32_t* c_len, int32_t heads,
+                             const float* q_dev, const float* k_dev, const float* v_dev, float* out_dev, void* stream);
 /* f5hip_op_layernorm: y = LN(x) * (gain_off + scale) + shift (AdaLN: gain_off 1; affine LN: gain_off 0; F/model/modules.py:285-290),
  *   rms = 1: x-transformers RMSNorm y = x / max(|x|_2, 1e-12) * sqrt(D) * scale.  All fp32 [M][D] / [D]. */
 int f5hip_op_layernorm(int32_t M, int32_t D, const float* x_dev, const float* scale_dev, const float* shift_dev, float gain_off, float eps,

@@ -247,3 +247,35 @@ def test_conv1d_vs_torch(impl, prec, tol, ci, co, k, dil, batch, P, T):
     err = (got - ref).abs().max().item()
     print(f"[parity] conv1d impl {impl} prec {prec} ci {ci} co {co} k {k} dil {dil}: max err {err:.3e} (ref rms {ref.pow(2).mean().sqrt():.3f})")
     assert err < tol
+
+
+# ---------------------------------------------------------------------------------------------------------------- MMDiT joint attention
+@pytest.mark.parametrize("x_len,c_len,x_kv", [([300], [21], None), ([1404, 257, 64], [240, 65, 7], [1404, 200, 33]), ([130, 129], [128, 1], [100, 129])])
+def test_joint_attention_vs_torch(x_len, c_len, x_kv):
+    """attn3's two-range kernels (keys = audio rows then text rows of the same sequence; queries from either) vs fp64 torch SDPA over
+    the concatenation, padding masked on the audio keys only (F/model/modules.py:506-514).  Same operand rounding and tolerance as the
+    single-range attention test."""
+    from tts_indic_server_f5_amd import ops
+    heads, D = 4, 256
+    g = torch.Generator().manual_seed(500 + sum(x_len))
+    Fx, Fc = sum(x_len), sum(c_len)
+    q, k, v = (torch.randn(Fx + Fc, D, generator=g) for _ in range(3))
+    out = ops.joint_attention(q.to(DEV), k.to(DEV), v.to(DEV), x_len, c_len, x_kv, heads=heads).cpu()
+    bf = lambda t: t.to(torch.bfloat16).double()
+    ox, oc = 0, Fx
+    worst = 0.0
+    for i, (n, nt) in enumerate(zip(x_len, c_len)):
+        sel = torch.cat([torch.arange(ox, ox + n), torch.arange(oc, oc + nt)])
+        qq = bf(q[sel] * 0.125).view(n + nt, heads, 64).transpose(0, 1)
+        kk = bf(k[sel]).view(n + nt, heads, 64).transpose(0, 1)
+        vv = bf(v[sel]).view(n + nt, heads, 64).transpose(0, 1)
+        s = qq @ kk.transpose(1, 2)
+        kv = n if x_kv is None else x_kv[i]
+        key_ok = torch.cat([torch.arange(n) < kv, torch.ones(nt, dtype=torch.bool)])
+        s = s.masked_fill(~key_ok[None, None, :], float("-inf"))
+        ref = (torch.softmax(s, dim=-1) @ vv).transpose(0, 1).reshape(n + nt, D)
+        err = (out[sel].double() - ref).abs().max().item()
+        worst = max(worst, err)
+        ox += n; oc += nt
+    print(f"[parity] joint attention x {x_len} c {c_len} kv {x_kv}: max err {worst:.3e}")
+    assert worst < 2e-2   # bf16 P and V operands (8 mantissa bits) over up to ~1.6 k keys; the single-range test uses the same bound

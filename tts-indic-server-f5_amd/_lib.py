@@ -54,6 +54,7 @@ SYMBOLS = {
     "f5hip_op_attention": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                      C.POINTER(C.c_double), C.c_void_p]),
     "f5hip_op_layernorm": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int32, C.c_void_p, C.c_void_p]),
+    "f5hip_op_joint_attention": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "f5hip_op_conv1d": (C.c_int, [C.c_int32] * 7 + [C.c_void_p] * 5 + [C.c_int32] * 3 + [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "f5hip_vocos_create": (C.c_void_p, [C.POINTER(VocosConfig)]),
     "f5hip_vocos_destroy": (None, [C.c_void_p]),

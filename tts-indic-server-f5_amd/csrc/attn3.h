@@ -12,13 +12,17 @@
 // NW = waves per workgroup = 32-query slices per query tile (4, 6 or 8).  The launcher picks NW so that the grid fills the 256 CUs in
 // whole rounds: at the C2 shape (2 sequences x 16 heads x 1404 queries) 256-query tiles give 192 workgroups -- 64 CUs idle for the whole
 // launch -- while 192-query tiles (NW = 6) give exactly 256 workgroups with 3/4 of the work each.
-template <int NW>
+// SEG2: the keys are two row ranges (AttnArgs::seq_kv_row0 / seq_kv2_*): tile kt covers 64 rows of the first range while kt < nkt1, of
+// the second after it; the last tile of EACH range is masked.  SEG2 = false is the single-range kernel of the DiT / UNetT path, unchanged.
+template <int NW, bool SEG2 = false>
 static __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn3_fwd_kernel(const AttnArgs p) {
     constexpr int NST = 5, STAGE = 16384;
     constexpr int P_HI = (16 + NW - 1) / NW, P_LO = 16 / NW;   // 1 KiB pieces of a KV tile per wave (pieces w, w + NW, ...)
     __shared__ __attribute__((aligned(16))) char smem[NST * STAGE];
     const int seq = blockIdx.z, head = blockIdx.y;
     const int len = p.seq_len[seq], kvlen = p.seq_kvlen[seq], row0 = p.seq_row0[seq];
+    const int kv_row0 = SEG2 ? p.seq_kv_row0[seq] : row0, kv2_row0 = SEG2 ? p.seq_kv2_row0[seq] : 0, kv2_len = SEG2 ? p.seq_kv2_len[seq] : 0;
+    const int nkt1 = (kvlen + 63) >> 6;
     const int q0 = blockIdx.x * (32 * NW);
     if (q0 >= len) return;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -50,16 +54,18 @@ static __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
         const int prow = (pc & 7) * 8 + (lane >> 3);
         const int chunk = (lane & 7) ^ ((prow >> 1) & 7);
         const bool isK = pc < 8;
-        src[j] = isK ? reinterpret_cast<const char*>(p.qk + (size_t)(row0 + prow) * (2 * D) + D + head * 64 + chunk * 8)
-                     : reinterpret_cast<const char*>(p.vt + (size_t)(head * 64 + prow) * p.ldvt + row0 + chunk * 8);
+        src[j] = isK ? reinterpret_cast<const char*>(p.qk + (size_t)(kv_row0 + prow) * (2 * D) + D + head * 64 + chunk * 8)
+                     : reinterpret_cast<const char*>(p.vt + (size_t)(head * 64 + prow) * p.ldvt + kv_row0 + chunk * 8);
         step[j] = isK ? (size_t)64 * (2 * D) * 2 : (size_t)64 * 2;   // bytes per KV tile
     }
     auto issue_tile = [&](int kt) {
         char* dst = smem + (kt % NST) * STAGE + wave * 1024;
+        // tile kt starts (in rows, relative to kv_row0) at 64 kt in the first range, at kv2_row0 - kv_row0 + 64 (kt - nkt1) in the second
+        const long long rel = (!SEG2 || kt < nkt1) ? (long long)kt * 64 : (long long)(kv2_row0 - kv_row0) + (long long)(kt - nkt1) * 64;
 #pragma unroll
         for (int j = 0; j < P_HI; j++)
             if (j < P_LO || wave + NW * j < 16)
-                attn_lds_dma16(src[j] + kt * step[j], dst + j * NW * 1024);   // (asm: keeps hipcc's lgkmcnt waits exact, see attn_common.h)
+                attn_lds_dma16(src[j] + rel * (long long)(step[j] / 64), dst + j * NW * 1024);   // (asm: keeps hipcc's lgkmcnt waits exact, see attn_common.h)
     };
     // this wave's pieces of a tile have landed when at most `newer` younger tiles of its own are in flight
     auto wait_landed = [&](int newer) {
@@ -77,7 +83,7 @@ static __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
         for (int g = 0; g < 16; g++) oacc[dt][g] = 0.0f;
     float mrun = -1e30f, lrun = 0.0f;
 
-    const int nkt = (kvlen + 63) >> 6;
+    const int nkt = nkt1 + (SEG2 ? (kv2_len + 63) >> 6 : 0);
 #pragma unroll
     for (int t = 0; t < NST - 1; t++)
         if (t < nkt) issue_tile(t);
@@ -95,13 +101,15 @@ static __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
                 s[kh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[sI], s[kh], 0, 0, 0);
             }
         }
-        if (kt * 64 + 64 > kvlen) {   // key-padding mask
+        // keys of this tile that exist: the rest of its range (a tile never straddles the two ranges)
+        const int valid = (!SEG2 || kt < nkt1) ? kvlen - kt * 64 : kv2_len - (kt - nkt1) * 64;
+        if (valid < 64) {   // key-padding mask
 #pragma unroll
             for (int kh = 0; kh < 2; kh++)
 #pragma unroll
                 for (int g = 0; g < 16; g++) {
-                    const int key = kt * 64 + kh * 32 + (g & 3) + 8 * (g >> 2) + 4 * fh;
-                    if (key >= kvlen) s[kh][g] = -1e30f;
+                    const int key = kh * 32 + (g & 3) + 8 * (g >> 2) + 4 * fh;
+                    if (key >= valid) s[kh][g] = -1e30f;
                 }
         }
     };

@@ -9,6 +9,12 @@ struct AttnArgs {
     const int* seq_row0;
     const int* seq_len;
     const int* seq_kvlen;
+    // two-segment keys (attn3 SEG2 kernels; MMDiT joint attention, F/model/modules.py:496-514): the keys of (pseudo-)sequence s are rows
+    // seq_kv_row0[s] .. + seq_kvlen[s] followed by rows seq_kv2_row0[s] .. + seq_kv2_len[s]; its queries are rows seq_row0[s] .. + seq_len[s],
+    // which may be either segment.  Segment starts are multiples of 8 rows (the V^T pieces are 16-byte aligned).
+    const int* seq_kv_row0;
+    const int* seq_kv2_row0;
+    const int* seq_kv2_len;
     __bf16* out_hi;     // [M_pad][D]
     __bf16* out_lo;     // may be null
     int f16_out;        // 1: out_hi receives one fp16 plane (A operand of the fp16 out-projection GEMM)

@@ -16,6 +16,13 @@ hipError_t f5_launch_attn3(const AttnArgs& a, int max_len, int heads, int n_seq,
         if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = nw; }
     }
     const dim3 grid((max_len + 32 * best - 1) / (32 * best), heads, n_seq);
+    if (a.seq_kv2_row0) {   // two key ranges per (pseudo-)sequence: MMDiT joint attention
+        if (!a.seq_kv_row0 || !a.seq_kv2_len) return hipErrorInvalidValue;
+        if (best == 8) hipLaunchKernelGGL((attn3_fwd_kernel<8, true>), grid, dim3(512), 0, st, a);
+        else if (best == 6) hipLaunchKernelGGL((attn3_fwd_kernel<6, true>), grid, dim3(384), 0, st, a);
+        else hipLaunchKernelGGL((attn3_fwd_kernel<4, true>), grid, dim3(256), 0, st, a);
+        return hipGetLastError();
+    }
     if (best == 8) hipLaunchKernelGGL(attn3_fwd_kernel<8>, grid, dim3(512), 0, st, a);
     else if (best == 6) hipLaunchKernelGGL(attn3_fwd_kernel<6>, grid, dim3(384), 0, st, a);
     else hipLaunchKernelGGL(attn3_fwd_kernel<4>, grid, dim3(256), 0, st, a);

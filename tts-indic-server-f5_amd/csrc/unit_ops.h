@@ -269,6 +269,61 @@ extern "C" int f5hip_op_attention(int32_t n_seq, const int32_t* seq_len, const i
 }
 
 
+// Joint attention of the MMDiT blocks (JointAttnProcessor, F/model/modules.py:496-522): per sequence the queries and the keys are the
+// audio rows followed by the text rows; padding is masked on the audio keys only (x_kvlen <= x_len valid audio keys, every text key).
+// q / k / v / out fp32 [sum(x_len) + sum(c_len)][64 heads]: all audio frames sequence by sequence, then all text tokens sequence by
+// sequence.  Runs the two-range attn3 kernels over 2 n_seq pseudo-sequences (audio queries, text queries) that share the key ranges.
+extern "C" int f5hip_op_joint_attention(int32_t n_seq, const int32_t* x_len, const int32_t* x_kvlen, const int32_t* c_len, int32_t heads,
+                                        const float* q_dev, const float* k_dev, const float* v_dev, float* out_dev, void* stream) {
+    if (n_seq <= 0 || !x_len || !c_len || heads <= 0 || !q_dev || !k_dev || !v_dev || !out_dev) return fail(-1, "op_joint_attention: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    const int D = heads * 64;
+    int Mx = 0, Mc = 0, Fx = 0, Fc = 0, max_len = 0;
+    for (int i = 0; i < n_seq; i++) {
+        if (x_len[i] <= 0 || x_len[i] > 4096 || c_len[i] <= 0 || c_len[i] > 4096 || (x_kvlen && (x_kvlen[i] <= 0 || x_kvlen[i] > x_len[i])))
+            return fail(-1, "op_joint_attention: bad lengths");
+        Mx += (x_len[i] + 127) / 128 * 128; Mc += (c_len[i] + 127) / 128 * 128; Fx += x_len[i]; Fc += c_len[i];
+        max_len = std::max(max_len, std::max((int)x_len[i], (int)c_len[i]));
+    }
+    const int M_pad = Mx + Mc, F = Fx + Fc, NS = 2 * n_seq;
+    std::vector<int> row_src(M_pad, -1), frame_row(F), meta(6 * NS);
+    for (int i = 0, rx = 0, rc = Mx, fx = 0, fc = Fx; i < n_seq; i++) {
+        for (int j = 0; j < x_len[i]; j++) { row_src[rx + j] = fx + j; frame_row[fx + j] = rx + j; }
+        for (int j = 0; j < c_len[i]; j++) { row_src[rc + j] = fc + j; frame_row[fc + j] = rc + j; }
+        for (int q = 0; q < 2; q++) {              // pseudo-sequence 2 i: audio queries, 2 i + 1: text queries
+            const int s = 2 * i + q;
+            meta[s] = q ? rc : rx;                                  // seq_row0
+            meta[NS + s] = q ? c_len[i] : x_len[i];                 // seq_len
+            meta[2 * NS + s] = x_kvlen ? x_kvlen[i] : x_len[i];     // seq_kvlen (first key range: audio)
+            meta[3 * NS + s] = rx;                                  // seq_kv_row0
+            meta[4 * NS + s] = rc;                                  // seq_kv2_row0
+            meta[5 * NS + s] = c_len[i];                            // seq_kv2_len
+        }
+        rx += (x_len[i] + 127) / 128 * 128; rc += (c_len[i] + 127) / 128 * 128; fx += x_len[i]; fc += c_len[i];
+    }
+    OpBufs b;
+    __bf16* qk = b.get<__bf16>((size_t)(M_pad + 256) * 2 * D); __bf16* vt = b.get<__bf16>((size_t)D * (M_pad + 256));
+    __bf16* ohi = b.get<__bf16>((size_t)(M_pad + 256) * D); __bf16* olo = b.get<__bf16>((size_t)(M_pad + 256) * D);
+    int* d_rs = b.get<int>(M_pad); int* d_fr = b.get<int>(F); int* d_meta = b.get<int>(6 * NS);
+    if (!qk || !vt || !ohi || !olo || !d_rs || !d_fr || !d_meta) return fail(-5, "op_joint_attention: hipMalloc");
+    if (hipMemcpyAsync(d_rs, row_src.data(), sizeof(int) * M_pad, hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipMemcpyAsync(d_fr, frame_row.data(), sizeof(int) * F, hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipMemcpyAsync(d_meta, meta.data(), sizeof(int) * 6 * NS, hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipMemsetAsync(qk, 0, sizeof(__bf16) * (size_t)(M_pad + 256) * 2 * D, st) != hipSuccess ||
+        hipMemsetAsync(vt, 0, sizeof(__bf16) * (size_t)D * (M_pad + 256), st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+        return fail(-6, "op_joint_attention: upload");
+    hipLaunchKernelGGL(op_pack_qkv_kernel, dim3(M_pad), dim3(256), 0, st, q_dev, k_dev, v_dev, D, d_rs, M_pad + 256, qk, vt);
+    AttnArgs at; memset(&at, 0, sizeof(at));
+    at.qk = qk; at.vt = vt; at.D = D; at.ldvt = M_pad + 256; at.seq_row0 = d_meta; at.seq_len = d_meta + NS; at.seq_kvlen = d_meta + 2 * NS;
+    at.seq_kv_row0 = d_meta + 3 * NS; at.seq_kv2_row0 = d_meta + 4 * NS; at.seq_kv2_len = d_meta + 5 * NS;
+    at.out_hi = ohi; at.out_lo = olo;
+    const hipError_t e = f5_launch_attn3(at, max_len, heads, NS, st);
+    if (e != hipSuccess) return fail(-7, "op_joint_attention launch: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(op_unpack_planes_kernel, dim3(F), dim3(256), 0, st, ohi, olo, D, d_fr, out_dev);
+    if (hipStreamSynchronize(st) != hipSuccess) return fail(-7, "op_joint_attention: %s", hipGetErrorString(hipGetLastError()));
+    return 0;
+}
+
 // One Conv1d of the BigVGAN kind over channel-last rows -- batch sequences of pitch P rows, T valid -- through the library's two paths:
 // impl 0 = gemm.h implicit GEMM (A window re-read per tap), 5 = conv5.h (window once in LDS).  x_dev fp32 [batch * P][c_in],
 // w_host [c_out][c_in][k], out_dev fp32 [batch * P][c_out] (= conv + bias + res).  prec 2 = split bf16, 3 = fp16.

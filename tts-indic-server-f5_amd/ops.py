@@ -96,3 +96,17 @@ def conv1d(x, weight, bias=None, res=None, *, batch, valid, dilation=1, prec=2, 
     _lib.check(_lib.lib().f5hip_op_conv1d(batch, P, valid, c_in, c_out, k, dilation, _p(x), _p(w), _p(b), _p(r), _p(out), prec, impl, iters,
                                           C.byref(us), _p(st), nblk, _lib.current_stream_ptr()), "f5hip_op_conv1d")
     return out, us.value, st
+
+
+def joint_attention(q, k, v, x_len, c_len, x_kvlen=None, *, heads):
+    """MMDiT joint attention: per sequence softmax(q [x ; c] k^T / 8 + mask on the padded audio keys) v over the concatenation of its audio
+    rows and its text rows.  q / k / v fp32 [sum(x_len) + sum(c_len), 64 * heads]: all audio frames first, then all text tokens."""
+    dev = q.device
+    q, k, v = (_f32(t, dev) for t in (q, k, v))
+    out = torch.empty_like(q)
+    xl = np.ascontiguousarray(np.asarray(x_len, dtype=np.int32))
+    cl = np.ascontiguousarray(np.asarray(c_len, dtype=np.int32))
+    kl = None if x_kvlen is None else np.ascontiguousarray(np.asarray(x_kvlen, dtype=np.int32))
+    _lib.check(_lib.lib().f5hip_op_joint_attention(len(xl), _p(xl), _p(kl), _p(cl), heads, _p(q), _p(k), _p(v), _p(out), _lib.current_stream_ptr()),
+               "f5hip_op_joint_attention")
+    return out
