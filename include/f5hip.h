@@ -33,7 +33,9 @@ typedef struct f5hip_dit_config {
                                 touches the ODE state / embeddings / U-skips (3.1e-4 mel RMS for F5-Base at 32 NFE, 4.9e-4 for E2-Base
                                 at 64 NFE, against the reference's own CFM.sample outputs: inside the 1e-3 bound);
                             1 = plain bf16 (fast, ~8e-3 mel RMS: outside the bound) */
-    int32_t arch;        /* 0 = DiT (F5-TTS, F/model/backbones/dit.py), 1 = UNetT (E2-TTS, F/model/backbones/unett.py: text_dim = mel_dim, conv_layers = 0) */
+    int32_t arch;        /* 0 = DiT (F5-TTS, F/model/backbones/dit.py), 1 = UNetT (E2-TTS, F/model/backbones/unett.py: text_dim = mel_dim, conv_layers = 0),
+                            2 = MMDiT (F/model/backbones/mmdit.py: text_dim = dim, conv_layers = 0; state_dict keys transformer.audio_embed.*,
+                                transformer.transformer_blocks.{i}.attn_norm_{c,x} / attn.to_{q,k,v}[_c] / attn.to_out[_c] / ff_{c,x}) */
 } f5hip_dit_config;
 
 typedef struct f5hip_dit f5hip_dit;

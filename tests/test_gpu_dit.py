@@ -159,6 +159,54 @@ def test_unett_small_forward_vs_reference_fixture(golden_dir, planes):
     assert e < 1e-3 * max(1.0, ref.pow(2).mean().sqrt().item())   # un-gated residual stream: output rms is > 1
 
 
+# ---------------------------------------------------------------- MMDiT, F/model/backbones/mmdit.py
+MMTINY = dict(dim=128, depth=3, heads=2, ff_mult=2, text_num_embeds=40)
+
+
+@pytest.mark.parametrize("planes", [2, 3], ids=["bf16x3", "mixed_f16"])
+def test_mmdit_tiny_vs_reference_fixture(golden_dir, planes):
+    """The dual-stream backbone against the reference's own MMDiT (two full blocks + the context-pre-only last one): forward at b = 1 and at
+    a padded b = 3 with mask (audio keys masked, text keys never), both CFG branches, the audio stream behind block 0, and CFM.sample."""
+    from tts_indic_server_f5_amd.model import F5HipModel, MMDiTArch
+    g = _load(golden_dir, "mmdit_tiny")
+    m = F5HipModel(MMDiTArch(**MMTINY), synth.mmdit_state_dict(**MMTINY), gemm_planes=planes)
+    mask = O.lens_to_mask(g["lens"], g["x"].shape[1])
+    for tag, da, dt in (("cond", False, False), ("null", True, True)):
+        out = m.transformer_forward(g["x"][:1], g["cond"][:1], g["text"][:1], float(g["time"]), da, dt)
+        assert _report("mmdit tiny forward b1 " + tag, out, g["out_b1_" + tag]) < 1e-3
+        out3 = m.transformer_forward(g["x"], g["cond"], g["text"], float(g["time"]), da, dt, mask=mask)
+        ref3 = g["out_b3_mask_" + tag]
+        keep = mask[..., None].expand_as(ref3)
+        assert _report("mmdit tiny forward b3 masked " + tag + " (valid rows)", out3.cpu()[keep], ref3[keep]) < 1e-3
+    hx = m.transformer_forward(g["x"][:1], g["cond"][:1], g["text"][:1], float(g["time"]), False, False, n_blocks=1)
+    assert _report("mmdit tiny audio stream behind block 0", hx, g["block0_x"]) < 1e-3
+    out, _ = m.sample(g["sample_cond"], g["sample_text"], 48, steps=8, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=7)
+    ref = g["sample_out"][:, 20:]
+    assert _report("mmdit tiny sample", out[:, 20:], ref) < 1e-3 * max(1.0, ref.pow(2).mean().sqrt().item())
+    assert torch.equal(out[:, :20].cpu(), g["sample_out"][:, :20])
+
+
+def test_mmdit_mid_size_vs_oracle():
+    """dim 512 / 8 heads / 4 blocks at 300 frames + 61 text positions, two sequences with a masked tail: the block GEMMs take the production
+    gemm5 path (K = 512), the joint attention runs 6 key tiles with partial last tiles in BOTH ranges.  Against the oracle (pinned by the
+    reference fixture above)."""
+    from tts_indic_server_f5_amd.model import F5HipModel, MMDiTArch
+    arch = dict(dim=512, depth=4, heads=8, ff_mult=2, text_num_embeds=100)
+    sd, cfg = synth.mmdit_state_dict(**arch), O.MMDiTConfig(**arch)
+    m = F5HipModel(MMDiTArch(**arch), sd)
+    g = torch.Generator().manual_seed(91)
+    b, n, nt = 2, 300, 61
+    x = torch.randn(b, n, 100, generator=g)
+    cond = torch.randn(b, n, 100, generator=g) * (torch.arange(n)[None, :, None] < 90)
+    text = torch.randint(0, 100, (b, nt), generator=g)
+    text[1, 40:] = -1
+    mask = O.lens_to_mask(torch.tensor([300, 233]), n)
+    ref = O.mmdit_forward(sd, cfg, x, cond, text, torch.tensor(0.6), False, False, mask=mask)
+    out = m.transformer_forward(x, cond, text, 0.6, False, False, mask=mask)
+    keep = mask[..., None].expand_as(ref)
+    assert _report("mmdit 512/8/4 forward, masked b = 2 (valid rows)", out.cpu()[keep], ref[keep]) < 1e-3
+
+
 def test_ragged_batch_is_per_item_batch1(tiny_model):
     """sample() on a ragged batch == each item sampled alone with the reference's batch-1 semantics (pad-free sharding,
     SURVEY Appendix B4), incl. edit_mask, cfg = 0 and a workspace that grows / shrinks between calls."""

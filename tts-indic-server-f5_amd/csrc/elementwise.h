@@ -70,12 +70,12 @@ __global__ __launch_bounds__(256) void grn_apply_kernel(const float* y, int ldy,
 // Text embedding gather (F/model/backbones/dit.py:48-64): e[m] = Embedding[id[m]] + pos_table[min(pos, 4095)]
 __global__ __launch_bounds__(256) void text_gather_kernel(const float* emb, const float* pos_table, int C, int M,
                                                           const int* row_token, const int* row_pos, int add_pos,
-                                                          float* out, int ldo) {
+                                                          float* out, int ldo, int max_pos) {
     const int row = blockIdx.x;
     if (row >= M) return;
     const int tok = row_token[row];
     if (tok < 0) return;   // padding row of the packed layout
-    const int pos = min(row_pos[row], 4095);
+    const int pos = min(row_pos[row], max_pos);   // get_pos_embed_indices clamps below the table length: 4096 (DiT), 1024 (MMDiT)
     for (int c = threadIdx.x; c < C; c += 256) {
         float v = emb[(size_t)tok * C + c];
         if (add_pos) v += pos_table[(size_t)pos * C + c];

@@ -49,11 +49,15 @@ struct f5hip_dit {
     // packed weights
     PackedW time1, time2, adaln, wx, wct, conv1, conv2, proj_out;
     std::vector<PackedW> wqkv, wout, wff1, wff2, wskip;   // wskip: UNetT skip projections (later half of the layers)
+    std::vector<PackedW> wqkv_c, wout_c, wff1_c, wff2_c;   // MMDiT text-stream weights (wout_c / wff*_c: all but the last, context-pre-only block)
+    std::vector<int> mod_c, mod_x;                         // MMDiT: offsets of the blocks' text / audio modulation vectors inside one row of `mod`
+    int mod_final = 0;
     std::vector<float*> g_attn, g_ff;                     // UNetT RMSNorm gains
     float *g_out = nullptr, *zeros = nullptr;
     std::vector<TextBlock> tblk;
     float *text_emb = nullptr, *text_pos = nullptr, *rope_cos = nullptr, *rope_sin = nullptr;
-    int arch = 0;     // 0 = DiT (F5-TTS), 1 = UNetT (E2-TTS): one extra row per sequence carries the time token
+    int arch = 0;     // 0 = DiT (F5-TTS), 1 = UNetT (E2-TTS): one extra row per sequence carries the time token, 2 = MMDiT: the text tokens of
+                      // every sequence are rows of their own stream, laid out behind all audio rows (rows [M, M + Mc))
     int td_pad = 0;   // text_dim rounded up to 32 (K padding of the step-invariant input-projection operand)
     int gw = 0;       // conv_pos_embed channels per group
     int n_adaln = 0;  // depth * 6 D + 2 D
@@ -72,6 +76,8 @@ struct f5hip_dit {
     int *d_row_pos, *d_row_start, *d_row_end, *d_row_seq, *d_row_token, *d_row_frame, *d_row_condframe, *d_row_keep,
         *d_seq_row0, *d_seq_len, *d_seq_kvlen, *d_urow_c, *d_urow_u, *d_frame_is_cond;
     int M = 0, M_pad = 0, n_seq = 0, n_frames = 0, max_len = 0;
+    int Mc = 0, Rtot = 0;   // MMDiT: text-stream rows and all rows (= row pitch of the V^T buffer); Rtot == M otherwise
+    int *d_j_row0 = nullptr, *d_j_len = nullptr, *d_j_kvlen = nullptr, *d_j_kv_row0 = nullptr, *d_j_kv2_row0 = nullptr, *d_j_kv2_len = nullptr;   // MMDiT joint attention: 2 n_seq pseudo-sequences
     bool any_masked = false;
     std::vector<int> h_seq_len;
 };
@@ -81,8 +87,9 @@ static int ceil_to(int v, int m) { return (v + m - 1) / m * m; }
 f5hip_dit* f5hip_dit_create(const f5hip_dit_config* cfg) {
     if (!cfg) { set_error("null config"); return nullptr; }
     if (cfg->dim % 128 || cfg->dim != cfg->heads * 64 || cfg->dim % 16 || cfg->text_dim % 4 || cfg->mel_dim > 128 || cfg->mel_dim % 4 ||
-        cfg->dim / 16 > 64 || cfg->gemm_planes < 1 || cfg->gemm_planes > 3 || cfg->arch < 0 || cfg->arch > 1 ||
-        (cfg->arch == 1 && (cfg->conv_layers != 0 || cfg->depth % 2)) || (cfg->conv_layers > 0 && cfg->text_dim % 32)) {
+        cfg->dim / 16 > 64 || cfg->gemm_planes < 1 || cfg->gemm_planes > 3 || cfg->arch < 0 || cfg->arch > 2 ||
+        (cfg->arch == 1 && (cfg->conv_layers != 0 || cfg->depth % 2)) || (cfg->conv_layers > 0 && cfg->text_dim % 32) ||
+        (cfg->arch == 2 && (cfg->conv_layers != 0 || cfg->text_dim != cfg->dim || cfg->depth < 1))) {
         set_error("unsupported backbone geometry (need dim %% 128 == 0, dim == 64*heads, dim/16 <= 64, mel_dim <= 128, text conv needs text_dim %% 32 == 0; UNetT: even depth, no text conv)");
         return nullptr;
     }
@@ -106,9 +113,18 @@ f5hip_dit* f5hip_dit_create(const f5hip_dit_config* cfg) {
         return nullptr;
     }
     *m->ln_err = 0;
-    m->td_pad = ceil_to(cfg->text_dim, 32);
+    m->td_pad = cfg->arch == 2 ? 0 : ceil_to(cfg->text_dim, 32);   // MMDiT: the text never enters the input projection (mmdit.py:64-70)
     m->gw = cfg->dim / 16;
     m->n_adaln = cfg->arch == 0 ? cfg->depth * 6 * cfg->dim + 2 * cfg->dim : 0;
+    if (cfg->arch == 2) {   // per block [text: 6 D, or 2 D in the last (context-pre-only) block][audio: 6 D], then the final 2 D
+        int off = 0;
+        for (int l = 0; l < cfg->depth; l++) {
+            m->mod_c.push_back(off); off += (l == cfg->depth - 1 ? 2 : 6) * cfg->dim;
+            m->mod_x.push_back(off); off += 6 * cfg->dim;
+        }
+        m->mod_final = off;
+        m->n_adaln = off + 2 * cfg->dim;
+    }
     return m;
 }
 
@@ -117,7 +133,7 @@ static void free_packed(PackedW& w) { dev_free(w.hi); dev_free(w.lo); dev_free(w
 void f5hip_dit_destroy(f5hip_dit* m) {
     if (!m) return;
     for (PackedW* w : {&m->time1, &m->time2, &m->adaln, &m->wx, &m->wct, &m->conv1, &m->conv2, &m->proj_out}) free_packed(*w);
-    for (auto* v : {&m->wqkv, &m->wout, &m->wff1, &m->wff2, &m->wskip}) for (auto& w : *v) free_packed(w);
+    for (auto* v : {&m->wqkv, &m->wout, &m->wff1, &m->wff2, &m->wskip, &m->wqkv_c, &m->wout_c, &m->wff1_c, &m->wff2_c}) for (auto& w : *v) free_packed(w);
     for (auto* v : {&m->g_attn, &m->g_ff}) for (float* g : *v) dev_free(g);
     dev_free(m->g_out); dev_free(m->zeros);
     for (auto& b : m->tblk) {
@@ -184,6 +200,24 @@ int f5hip_dit_finalize(f5hip_dit* m) {
         memcpy(&ba[(size_t)c.depth * 6 * D], bfin->data(), sizeof(float) * 2 * D);
         if (pack_linear(m->adaln, wa.data(), m->n_adaln, D, D, ba.data())) return -4;
     }
+    if (m->arch == 2) {   // MMDiTBlock: attn_norm_c (AdaLayerNormZero, or _Final in the last block) and attn_norm_x (F/model/modules.py:593-594)
+        std::vector<float> wa((size_t)m->n_adaln * D), ba(m->n_adaln);
+        for (int l = 0; l < c.depth; l++) {
+            const std::string p = T + "transformer_blocks." + std::to_string(l) + ".";
+            const int nc = (l == c.depth - 1 ? 2 : 6) * D;
+            GETP(wc, p + "attn_norm_c.linear.weight", (int64_t)nc * D); GETP(bc, p + "attn_norm_c.linear.bias", nc);
+            GETP(wxm, p + "attn_norm_x.linear.weight", (int64_t)6 * D * D); GETP(bxm, p + "attn_norm_x.linear.bias", 6 * D);
+            memcpy(&wa[(size_t)m->mod_c[l] * D], wc->data(), sizeof(float) * (size_t)nc * D);
+            memcpy(&ba[m->mod_c[l]], bc->data(), sizeof(float) * nc);
+            memcpy(&wa[(size_t)m->mod_x[l] * D], wxm->data(), sizeof(float) * (size_t)6 * D * D);
+            memcpy(&ba[m->mod_x[l]], bxm->data(), sizeof(float) * 6 * D);
+        }
+        GETP(wf, T + "norm_out.linear.weight", (int64_t)2 * D * D);
+        GETP(bfin, T + "norm_out.linear.bias", 2 * D);
+        memcpy(&wa[(size_t)m->mod_final * D], wf->data(), sizeof(float) * 2 * D * D);
+        memcpy(&ba[m->mod_final], bfin->data(), sizeof(float) * 2 * D);
+        if (pack_linear(m->adaln, wa.data(), m->n_adaln, D, D, ba.data())) return -4;
+    }
     // --- text embedding ---
     {
         GETP(e, T + "text_embed.text_embed.weight", (int64_t)(c.text_num_embeds + 1) * Td);
@@ -216,9 +250,10 @@ int f5hip_dit_finalize(f5hip_dit* m) {
     }
     // --- input projection split by source: x part (changes every step) | cond + text part (step invariant) ---
     {
-        const int Kin = 2 * mel + Td;
-        GETP(w, T + "input_embed.proj.weight", (int64_t)D * Kin);
-        GETP(b, T + "input_embed.proj.bias", D);
+        const bool mm = m->arch == 2;   // MMDiT: AudioEmbedding.linear over cat(x, cond) only (mmdit.py:60-70)
+        const int Kin = 2 * mel + (mm ? 0 : Td);
+        GETP(w, T + (mm ? "audio_embed.linear.weight" : "input_embed.proj.weight"), (int64_t)D * Kin);
+        GETP(b, T + (mm ? "audio_embed.linear.bias" : "input_embed.proj.bias"), D);
         const int Kct = 128 + m->td_pad;
         std::vector<float> wx((size_t)D * 128, 0.0f), wct((size_t)D * Kct, 0.0f);
         for (int n = 0; n < D; n++) {
@@ -226,7 +261,7 @@ int f5hip_dit_finalize(f5hip_dit* m) {
                 wx[(size_t)n * 128 + k] = (*w)[(size_t)n * Kin + k];
                 wct[(size_t)n * Kct + k] = (*w)[(size_t)n * Kin + mel + k];
             }
-            for (int k = 0; k < Td; k++) wct[(size_t)n * Kct + 128 + k] = (*w)[(size_t)n * Kin + 2 * mel + k];
+            for (int k = 0; k < (mm ? 0 : Td); k++) wct[(size_t)n * Kct + 128 + k] = (*w)[(size_t)n * Kin + 2 * mel + k];
         }
         if (pack_linear(m->wx, wx.data(), D, 128, 128, nullptr)) return -4;
         if (pack_linear(m->wct, wct.data(), D, Kct, Kct, b->data())) return -4;
@@ -234,7 +269,7 @@ int f5hip_dit_finalize(f5hip_dit* m) {
     // --- conv_pos_embed: grouped Conv1d(D, D, 31, groups 16) as 16 implicit GEMMs, each padded to 64 x (31 x 64) ---
     for (int which = 0; which < 2; which++) {
         const int gw = m->gw;
-        std::string p = T + "input_embed.conv_pos_embed.conv1d." + std::to_string(which * 2) + ".";
+        std::string p = T + (m->arch == 2 ? "audio_embed" : "input_embed") + ".conv_pos_embed.conv1d." + std::to_string(which * 2) + ".";
         GETP(w, p + "weight", (int64_t)D * gw * 31);
         GETP(b, p + "bias", D);
         const int K = 31 * 64;
@@ -251,10 +286,11 @@ int f5hip_dit_finalize(f5hip_dit* m) {
     // --- transformer blocks ---
     m->wqkv.resize(c.depth); m->wout.resize(c.depth); m->wff1.resize(c.depth); m->wff2.resize(c.depth);
     if (m->arch == 1) { m->wskip.resize(c.depth); m->g_attn.assign(c.depth, nullptr); m->g_ff.assign(c.depth, nullptr); }
+    if (m->arch == 2) { m->wqkv_c.resize(c.depth); m->wout_c.resize(c.depth); m->wff1_c.resize(c.depth); m->wff2_c.resize(c.depth); }
     for (int l = 0; l < c.depth; l++) {
         // DiT: transformer_blocks.{l}.attn.* / .ff.*  (F/model/modules.py:542-556);  UNetT: layers.{l}.{0 skip_proj, 1 attn_norm, 2 attn, 3 ff_norm, 4 ff}
-        const std::string p = T + (m->arch == 0 ? "transformer_blocks." : "layers.") + std::to_string(l) + ".";
-        const std::string pa = p + (m->arch == 0 ? "attn." : "2."), pf = p + (m->arch == 0 ? "ff." : "4.");
+        const std::string p = T + (m->arch != 1 ? "transformer_blocks." : "layers.") + std::to_string(l) + ".";
+        const std::string pa = p + (m->arch != 1 ? "attn." : "2."), pf = p + (m->arch == 0 ? "ff." : (m->arch == 2 ? "ff_x." : "4."));
         std::vector<float> wq((size_t)3 * D * D), bq(3 * D);
         const char* nm[3] = {"to_q", "to_k", "to_v"};
         for (int i = 0; i < 3; i++) {
@@ -270,6 +306,25 @@ int f5hip_dit_finalize(f5hip_dit* m) {
         if (pack_linear(m->wff1[l], w1->data(), F, D, D, b1->data(), 128, m->blk_f16)) return -4;
         GETP(w2, pf + "ff.2.weight", (int64_t)D * F); GETP(b2, pf + "ff.2.bias", D);
         if (pack_linear(m->wff2[l], w2->data(), D, F, F, b2->data(), 128, m->blk_f16)) return -4;
+        if (m->arch == 2) {   // the text stream's own projections (Attention(context_dim=...), F/model/modules.py:365-374) and feed-forward
+            std::vector<float> wqc((size_t)3 * D * D), bqc(3 * D);
+            const char* nmc[3] = {"to_q_c", "to_k_c", "to_v_c"};
+            for (int i = 0; i < 3; i++) {
+                GETP(w, pa + nmc[i] + ".weight", (int64_t)D * D);
+                GETP(b, pa + nmc[i] + ".bias", D);
+                memcpy(&wqc[(size_t)i * D * D], w->data(), sizeof(float) * D * D);
+                memcpy(&bqc[(size_t)i * D], b->data(), sizeof(float) * D);
+            }
+            if (pack_linear(m->wqkv_c[l], wqc.data(), 3 * D, D, D, bqc.data(), 128, m->blk_f16)) return -4;
+            if (l < c.depth - 1) {
+                GETP(woc, pa + "to_out_c.weight", (int64_t)D * D); GETP(boc, pa + "to_out_c.bias", D);
+                if (pack_linear(m->wout_c[l], woc->data(), D, D, D, boc->data(), 128, m->blk_f16)) return -4;
+                GETP(w1c, p + "ff_c.ff.0.0.weight", (int64_t)F * D); GETP(b1c, p + "ff_c.ff.0.0.bias", F);
+                if (pack_linear(m->wff1_c[l], w1c->data(), F, D, D, b1c->data(), 128, m->blk_f16)) return -4;
+                GETP(w2c, p + "ff_c.ff.2.weight", (int64_t)D * F); GETP(b2c, p + "ff_c.ff.2.bias", D);
+                if (pack_linear(m->wff2_c[l], w2c->data(), D, F, F, b2c->data(), 128, m->blk_f16)) return -4;
+            }
+        }
         if (m->arch == 1) {
             GETP(ga, p + "1.g", D); GETP(gf, p + "3.g", D);
             if (upload_f32(&m->g_attn[l], ga->data(), D) || upload_f32(&m->g_ff[l], gf->data(), D)) return -4;
@@ -339,7 +394,7 @@ static int ensure_workspace(f5hip_dit* m, int rows_pad, int frames, int n_seq) {
         }
     }
     m->cap_rows = (int)R; m->cap_frames = (int)U; m->cap_seq = (int)S;
-    const int need = (int)(R * 8 + S * 3 + U * 3 + 64);
+    const int need = (int)(R * 8 + S * 15 + U * 3 + 64);
     if (need > m->meta_cap) {
         dev_free(m->meta);
         if (hipMalloc((void**)&m->meta, sizeof(int) * need) != hipSuccess) { m->meta = nullptr; m->meta_cap = 0; return fail(-5, "hipMalloc meta"); }
@@ -348,18 +403,25 @@ static int ensure_workspace(f5hip_dit* m, int rows_pad, int frames, int n_seq) {
     return 0;
 }
 
-struct SeqDesc { int len, kvlen, frame0 /* first frame in caller's packed arrays */, text_row, drop_audio, drop_text, branch /* 0 cond, 1 uncond */; };
+struct SeqDesc { int len, kvlen, frame0 /* first frame in caller's packed arrays */, text_row, drop_audio, drop_text, branch /* 0 cond, 1 uncond */;
+                 int c_len = 0 /* MMDiT: rows of the text stream (tokens incl. filler positions, as the reference's [b, nt] text tensor has them) */; };
 
 // Lays the sequences out (each padded to a multiple of 128 rows), builds the per-row metadata and uploads it.
 // UNetT: row 0 of every sequence is the time token (F/model/backbones/unett.py:184); frames follow at rows 1..len.
 static int setup_sequences(f5hip_dit* m, const std::vector<SeqDesc>& seqs, int n_frames, const int32_t* text, int nt_max,
                            const uint8_t* frame_is_cond, hipStream_t st) {
     const int extra = m->arch == 1 ? 1 : 0;
-    int rows = 0;
+    const bool mm = m->arch == 2;
+    int rows = 0, rows_x = 0;
     for (auto& s : seqs) rows += ceil_to(s.len + extra, 128);
+    rows_x = rows;
+    if (mm) for (auto& s : seqs) {
+        if (s.c_len <= 0 || s.c_len > 4096) return fail(-1, "MMDiT: a sequence needs 1..4096 text positions (got %d)", s.c_len);
+        rows += ceil_to(s.c_len, 128);
+    }
     if (ensure_workspace(m, rows, n_frames, (int)seqs.size())) return -5;
     const int R = rows, S = (int)seqs.size(), U = n_frames;
-    std::vector<int> hbuf((size_t)R * 8 + S * 3 + U * 3, 0);
+    std::vector<int> hbuf((size_t)R * 8 + S * 3 + U * 3 + (mm ? 12 * S : 0), 0);
     int* row_pos = &hbuf[0]; int* row_start = row_pos + R; int* row_end = row_start + R; int* row_seq = row_end + R;
     int* row_token = row_seq + R; int* row_frame = row_token + R; int* row_condframe = row_frame + R; int* row_keep = row_condframe + R;
     int* seq_row0 = row_keep + R; int* seq_len = seq_row0 + S; int* seq_kvlen = seq_len + S;
@@ -392,6 +454,31 @@ static int setup_sequences(f5hip_dit* m, const std::vector<SeqDesc>& seqs, int n
         }
         r0 += ceil_to(q.len + extra, 128);
     }
+    int* jm = fic + U;   // MMDiT joint attention: 6 arrays of 2 S pseudo-sequences (2 s: audio queries of sequence s, 2 s + 1: its text queries)
+    if (mm) {
+        int rc0 = rows_x;
+        for (int s = 0; s < S; s++) {
+            const SeqDesc& q = seqs[s];
+            for (int i = 0; i < q.c_len; i++) {
+                const int r = rc0 + i;
+                int tok = 0;   // filler (the reference feeds text + 1 with -1 padding -> 0; all ids 0 when the text is dropped: mmdit.py:38-40)
+                if (!q.drop_text && i < nt_max) tok = text[(size_t)q.text_row * nt_max + i] + 1;
+                if (tok < 0 || tok > m->cfg.text_num_embeds) return fail(-1, "text token %d of sequence %d is outside the vocabulary (0..%d)", tok - 1, s, m->cfg.text_num_embeds - 1);
+                row_pos[r] = i; row_seq[r] = s; row_token[r] = tok; row_keep[r] = 1; row_start[r] = rc0; row_end[r] = rc0 + q.c_len;
+            }
+            for (int qd = 0; qd < 2; qd++) {
+                const int j = 2 * s + qd;
+                jm[j] = qd ? rc0 : seq_row0[s];                 // query rows
+                jm[2 * S + j] = qd ? q.c_len : q.len;
+                jm[4 * S + j] = q.kvlen;                        // first key range: the audio rows, padding masked
+                jm[6 * S + j] = seq_row0[s];
+                jm[8 * S + j] = rc0;                            // second key range: the text rows, never masked (F/model/modules.py:508)
+                jm[10 * S + j] = q.c_len;
+            }
+            m->max_len = std::max(m->max_len, q.c_len);
+            rc0 += ceil_to(q.c_len, 128);
+        }
+    }
     if (hipMemcpyAsync(m->meta, hbuf.data(), sizeof(int) * hbuf.size(), hipMemcpyHostToDevice, st) != hipSuccess)
         return fail(-6, "metadata upload");
     if (hipStreamSynchronize(st) != hipSuccess) return fail(-6, "metadata upload sync");   // hbuf is a stack-scoped host buffer
@@ -401,7 +488,9 @@ static int setup_sequences(f5hip_dit* m, const std::vector<SeqDesc>& seqs, int n
     d += 8 * R;
     m->d_seq_row0 = d; m->d_seq_len = d + S; m->d_seq_kvlen = d + 2 * S; d += 3 * S;
     m->d_urow_c = d; m->d_urow_u = d + U; m->d_frame_is_cond = d + 2 * U;
-    m->M = R; m->M_pad = R; m->n_seq = S; m->n_frames = U;
+    d += 3 * U;
+    m->d_j_row0 = d; m->d_j_len = d + 2 * S; m->d_j_kvlen = d + 4 * S; m->d_j_kv_row0 = d + 6 * S; m->d_j_kv2_row0 = d + 8 * S; m->d_j_kv2_len = d + 10 * S;
+    m->M = rows_x; m->M_pad = rows_x; m->Mc = R - rows_x; m->Rtot = R; m->n_seq = S; m->n_frames = U;
     return 0;
 }
 
@@ -608,8 +697,15 @@ static int precompute_text_and_ce(f5hip_dit* m, const float* cond_dev, hipStream
     const f5hip_dit_config& c = m->cfg;
     const int D = c.dim, Td = c.text_dim, M = m->M, Kct = 128 + m->td_pad;
     prof_begin(PROF_OTHER, st);
-    hipLaunchKernelGGL(text_gather_kernel, dim3(M), dim3(256), 0, st, m->text_emb, m->text_pos, Td, M, m->d_row_token,
-                       m->d_row_pos, c.conv_layers > 0 ? 1 : 0, m->te, Td);
+    if (m->arch == 2) {
+        // MMDiT TextEmbedding (mmdit.py:37-52): embedding + absolute position table for the rows of the text stream (rows [M, M + Mc) of
+        // every per-row buffer); step invariant, copied into the stream at the start of each forward.  Padding rows stay zero.
+        hipLaunchKernelGGL(text_gather_kernel, dim3(m->Mc), dim3(256), 0, st, m->text_emb, m->text_pos, D, m->Mc, m->d_row_token + M,
+                           m->d_row_pos + M, 1, m->te + (size_t)M * D, D, 1023);
+    } else {
+        hipLaunchKernelGGL(text_gather_kernel, dim3(M), dim3(256), 0, st, m->text_emb, m->text_pos, Td, M, m->d_row_token,
+                           m->d_row_pos, c.conv_layers > 0 ? 1 : 0, m->te, Td, 4095);
+    }
     CKL("text_gather");
     // audio-cond columns of the step-invariant operand (zero rows for dropped cond / non-cond frames / padding)
     hipLaunchKernelGGL(split_rows_kernel, dim3(M), dim3(256), 0, st, cond_dev, c.mel_dim, c.mel_dim, M, m->d_row_condframe,
@@ -639,7 +735,7 @@ static int precompute_text_and_ce(f5hip_dit* m, const float* cond_dev, hipStream
         if (i == c.conv_layers - 1) { g2.out_hi = m->act.hi + 128; g2.out_lo = m->act.lo + 128; g2.ldob = Kct; }
         CK(run_gemm(m, g2, b.pw2, EPI_GENERIC, false, 128, st));
     }
-    if (c.conv_layers == 0) {
+    if (c.conv_layers == 0 && m->arch != 2) {   // (MMDiT: the text is not an input of the audio projection)
         prof_begin(PROF_OTHER, st);
         hipLaunchKernelGGL(split_rows_kernel, dim3(M), dim3(256), 0, st, m->te, Td, Td, M, (const int*)nullptr, m->act.hi,
                            m->act.lo, Kct, 128);
@@ -692,8 +788,14 @@ static int precompute_time(f5hip_dit* m, const float* t_host, int n_t, hipStream
 static int launch_attention(f5hip_dit* m, hipStream_t st) {
     const f5hip_dit_config& c = m->cfg;
     AttnArgs at; memset(&at, 0, sizeof(at));
-    at.qk = m->qk; at.vt = m->vt; at.D = c.dim; at.ldvt = m->M_pad; at.seq_row0 = m->d_seq_row0; at.seq_len = m->d_seq_len;
+    at.qk = m->qk; at.vt = m->vt; at.D = c.dim; at.ldvt = m->Rtot; at.seq_row0 = m->d_seq_row0; at.seq_len = m->d_seq_len;
     at.seq_kvlen = m->d_seq_kvlen; at.out_hi = m->ao.hi; at.out_lo = m->nsplit == 2 ? m->ao.lo : nullptr; at.f16_out = m->blk_f16 ? 1 : 0;
+    int n_att = m->n_seq;
+    if (m->arch == 2) {   // joint attention: audio and text queries of a sequence over its audio keys followed by its text keys
+        at.seq_row0 = m->d_j_row0; at.seq_len = m->d_j_len; at.seq_kvlen = m->d_j_kvlen;
+        at.seq_kv_row0 = m->d_j_kv_row0; at.seq_kv2_row0 = m->d_j_kv2_row0; at.seq_kv2_len = m->d_j_kv2_len;
+        n_att = 2 * m->n_seq;
+    }
     prof_begin(PROF_ATTN, st);
 #ifdef F5HIP_EXPERIMENTS
     static int attn_impl = -1;
@@ -704,7 +806,7 @@ static int launch_attention(f5hip_dit* m, hipStream_t st) {
 #endif
     {
         static const int attn_sel = getenv("F5HIP_ATTN") ? atoi(getenv("F5HIP_ATTN")) : 3;   // 4 = experiments/attn4.h (A/B in -DF5HIP_EXPERIMENTS builds)
-        const hipError_t e = attn_sel == 4 ? f5_launch_attn4(at, m->max_len, c.heads, m->n_seq, st) : f5_launch_attn3(at, m->max_len, c.heads, m->n_seq, st);
+        const hipError_t e = attn_sel == 4 && m->arch != 2 ? f5_launch_attn4(at, m->max_len, c.heads, n_att, st) : f5_launch_attn3(at, m->max_len, c.heads, n_att, st);
         if (e != hipSuccess) { prof_end(PROF_ATTN, st); return fail(-7, "attention launch: %s", hipGetErrorString(e)); }
     }
     prof_end(PROF_ATTN, st);
@@ -747,7 +849,7 @@ static int forward_unett_layers(f5hip_dit* m, int ti, int n_blocks, hipStream_t 
         ln.scale = m->g_attn[l];
         ln.f16_out = m->blk_f16 ? 1 : 0;   // block norms feed the fp16 block GEMMs in mixed mode; the final norm (proj_out) stays split bf16
         GemmArgs q = gemm_base(m->hn, D, m->wqkv[l], M);
-        q.D = D; q.row_pos = m->d_row_pos; q.rope_cos = m->rope_cos; q.rope_sin = m->rope_sin; q.qk = m->qk; q.vt = m->vt; q.ldvt = m->M_pad;
+        q.D = D; q.row_pos = m->d_row_pos; q.rope_cos = m->rope_cos; q.rope_sin = m->rope_sin; q.qk = m->qk; q.vt = m->vt; q.ldvt = m->Rtot;
         CK(run_ln(ln, st));
         CK(run_gemm(m, q, m->wqkv[l], EPI_QKV, false, 128, st));
         CK(launch_attention(m, st));
@@ -815,6 +917,72 @@ static void debug_dump_qkv(f5hip_dit* m, hipStream_t st) {
 
 // One DiT evaluation at time index ti for all laid-out sequences.  xs (split bf16 of x) must be current.
 // n_blocks < 0: full network, result in m->pred [M][128];  else stops after n_blocks blocks, result in m->h.
+// MMDiT blocks (F/model/modules.py:614-642, JointAttnProcessor :460-536): two residual streams -- the audio rows [0, M) in m->h and the
+// text rows [M, M + Mc) behind them in the same buffers -- with their own modulation, QKV, output and feed-forward weights and ONE
+// joint attention per block over [audio keys ; text keys] (rotary on head 0 of each stream with its own positions).  The last block is
+// context-pre-only: the text stream is only normalised and projected to q / k / v, then dropped.
+static int forward_mmdit_layers(f5hip_dit* m, int ti, int n_blocks, hipStream_t st) {
+    const f5hip_dit_config& c = m->cfg;
+    const int D = c.dim, F = c.ff_mult * D, M = m->M, Mc = m->Mc;
+    const float* mod = m->mod + (size_t)ti * m->n_adaln;
+    const size_t ro = (size_t)M;                                   // first text row
+    // the text stream starts every forward from its step-invariant embedding
+    if (hipMemcpyAsync(m->h + ro * D, m->te + ro * D, sizeof(float) * (size_t)Mc * D, hipMemcpyDeviceToDevice, st) != hipSuccess) return fail(-6, "MMDiT: text stream copy");
+    const Plane2 hn_c{m->hn.hi + ro * D, m->hn.lo + ro * D}, ao_c{m->ao.hi + ro * D, m->ao.lo + ro * D}, ff_c{m->ff.hi + ro * F, m->ff.lo + ro * F};
+    auto ln_for = [&](bool text, const float* shift, const float* scale, bool f16) {
+        LnArgs ln; memset(&ln, 0, sizeof(ln));
+        ln.x = m->h + (text ? ro * D : 0); ln.ldx = D; ln.M = text ? Mc : M; ln.D = D; ln.shift = shift; ln.scale = scale; ln.gain_off = 1.0f; ln.eps = 1e-6f;
+        ln.out_hi = text ? hn_c.hi : m->hn.hi; ln.out_lo = text ? hn_c.lo : m->hn.lo; ln.ldo = D; ln.f16_out = f16 ? 1 : 0;
+        return ln;
+    };
+    const int nb = n_blocks < 0 ? c.depth : n_blocks;
+    for (int l = 0; l < nb; l++) {
+        const bool last = l == c.depth - 1;
+        const float* mc = mod + m->mod_c[l];                       // text: shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp; last block: scale, shift
+        const float* mx = mod + m->mod_x[l];
+        CK(run_ln(last ? ln_for(true, mc + D, mc, m->blk_f16) : ln_for(true, mc, mc + D, m->blk_f16), st));
+        CK(run_ln(ln_for(false, mx, mx + D, m->blk_f16), st));
+        GemmArgs q = gemm_base(m->hn, D, m->wqkv[l], M);
+        q.D = D; q.row_pos = m->d_row_pos; q.rope_cos = m->rope_cos; q.rope_sin = m->rope_sin; q.qk = m->qk; q.vt = m->vt; q.ldvt = m->Rtot;
+        CK(run_gemm(m, q, m->wqkv[l], EPI_QKV, false, 128, st, M));
+        GemmArgs qc = gemm_base(hn_c, D, m->wqkv_c[l], Mc);
+        qc.D = D; qc.row_pos = m->d_row_pos + ro; qc.rope_cos = m->rope_cos; qc.rope_sin = m->rope_sin;
+        qc.qk = m->qk + ro * 2 * D; qc.vt = m->vt + ro; qc.ldvt = m->Rtot;
+        CK(run_gemm(m, qc, m->wqkv_c[l], EPI_QKV, false, 128, st, Mc));
+        CK(launch_attention(m, st));
+        GemmArgs o = gemm_base(m->ao, D, m->wout[l], M);
+        o.mul = mx + 2 * D; o.res = m->h; o.ldres = D; o.out_f32 = m->h; o.ldo = D;
+        o.row_keep = m->any_masked ? m->d_row_keep : nullptr;
+        CK(run_gemm(m, o, m->wout[l], EPI_GENERIC, false, 64, st, M));
+        if (!last) {
+            GemmArgs oc = gemm_base(ao_c, D, m->wout_c[l], Mc);
+            oc.mul = mc + 2 * D; oc.res = m->h + ro * D; oc.ldres = D; oc.out_f32 = m->h + ro * D; oc.ldo = D;
+            CK(run_gemm(m, oc, m->wout_c[l], EPI_GENERIC, false, 64, st, Mc));
+            CK(run_ln(ln_for(true, mc + 3 * D, mc + 4 * D, m->blk_f16), st));
+            GemmArgs f1c = gemm_base(hn_c, D, m->wff1_c[l], Mc);
+            f1c.act = ACT_GELU_TANH; f1c.out_hi = ff_c.hi; f1c.out_lo = ff_c.lo; f1c.ldob = F; f1c.f16_out = m->blk_f16 ? 1 : 0;
+            CK(run_gemm(m, f1c, m->wff1_c[l], EPI_GENERIC, false, 128, st, Mc));
+            GemmArgs f2c = gemm_base(ff_c, F, m->wff2_c[l], Mc);
+            f2c.mul = mc + 5 * D; f2c.res = m->h + ro * D; f2c.ldres = D; f2c.out_f32 = m->h + ro * D; f2c.ldo = D;
+            CK(run_gemm(m, f2c, m->wff2_c[l], EPI_GENERIC, false, 64, st, Mc));
+        }
+        CK(run_ln(ln_for(false, mx + 3 * D, mx + 4 * D, m->blk_f16), st));
+        GemmArgs f1 = gemm_base(m->hn, D, m->wff1[l], M);
+        f1.act = ACT_GELU_TANH; f1.out_hi = m->ff.hi; f1.out_lo = m->ff.lo; f1.ldob = F; f1.f16_out = m->blk_f16 ? 1 : 0;
+        CK(run_gemm(m, f1, m->wff1[l], EPI_GENERIC, false, 128, st, M));
+        GemmArgs f2 = gemm_base(m->ff, F, m->wff2[l], M);
+        f2.mul = mx + 5 * D; f2.res = m->h; f2.ldres = D; f2.out_f32 = m->h; f2.ldo = D;
+        CK(run_gemm(m, f2, m->wff2[l], EPI_GENERIC, false, 64, st, M));
+    }
+    if (n_blocks >= 0) return 0;
+    const float* mf = mod + m->mod_final;                          // (scale, shift): F/model/modules.py:308
+    CK(run_ln(ln_for(false, mf + D, mf, false), st));
+    GemmArgs po = gemm_base(m->hn, D, m->proj_out, M);
+    po.out_f32 = m->pred; po.ldo = 128;
+    CK(run_gemm(m, po, m->proj_out, EPI_GENERIC, false, 128, st, M));
+    return 0;
+}
+
 static int forward_step(f5hip_dit* m, int ti, int n_blocks, hipStream_t st) {
     const f5hip_dit_config& c = m->cfg;
     const int D = c.dim, F = c.ff_mult * D, M = m->M;
@@ -838,6 +1006,7 @@ static int forward_step(f5hip_dit* m, int ti, int n_blocks, hipStream_t st) {
 
     const int nb = n_blocks < 0 ? c.depth : n_blocks;
     if (m->arch == 1) return forward_unett_layers(m, ti, n_blocks, st);
+    if (m->arch == 2) return forward_mmdit_layers(m, ti, n_blocks, st);
     // Every LayerNorm but the first is launched together with the residual GEMM in front of it (run_gemm_ln: one kernel where the launch
     // is exact-fit): the out projection carries norm 2 of its block, FF2 carries norm 1 of the next block or the final norm.
     const float* mf = mod + (size_t)c.depth * 6 * D;   // final (scale, shift): F/model/modules.py:308
@@ -851,7 +1020,7 @@ static int forward_step(f5hip_dit* m, int ti, int n_blocks, hipStream_t st) {
     for (int l = 0; l < nb; l++) {
         const float* ml = mod + (size_t)l * 6 * D;   // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
         GemmArgs q = gemm_base(m->hn, D, m->wqkv[l], M);
-        q.D = D; q.row_pos = m->d_row_pos; q.rope_cos = m->rope_cos; q.rope_sin = m->rope_sin; q.qk = m->qk; q.vt = m->vt; q.ldvt = m->M_pad;
+        q.D = D; q.row_pos = m->d_row_pos; q.rope_cos = m->rope_cos; q.rope_sin = m->rope_sin; q.qk = m->qk; q.vt = m->vt; q.ldvt = m->Rtot;
         CK(run_gemm(m, q, m->wqkv[l], EPI_QKV, false, 128, st));
         static const int dump_qkv = getenv("F5HIP_DUMP_QKV") ? atoi(getenv("F5HIP_DUMP_QKV")) : -1;   // diagnostics, read once
         if (dump_qkv >= 0 && l == dump_qkv / 100 && ti == dump_qkv % 100) debug_dump_qkv(m, st);
@@ -902,6 +1071,7 @@ int f5hip_dit_forward(f5hip_dit* m, int32_t n_seq, const int32_t* seq_len, const
     for (int i = 0; i < n_seq; i++) {
         if (seq_len[i] <= 0 || seq_len[i] > 4096) return fail(-1, "seq_len[%d] = %d out of range", i, seq_len[i]);
         seqs[i] = {seq_len[i], kv_len ? kv_len[i] : seq_len[i], f0, i, drop_audio_cond ? drop_audio_cond[i] : 0, drop_text ? drop_text[i] : 0, 0};
+        seqs[i].c_len = nt_max;   // MMDiT.forward embeds every position of its [b, nt] text tensor, fillers included (mmdit.py:37-52, no text mask)
         if (seqs[i].kvlen <= 0 || seqs[i].kvlen > seqs[i].len) return fail(-1, "kv_len[%d] out of range", i);
         m->h_seq_len[i] = seq_len[i];
         f0 += seq_len[i];
@@ -967,10 +1137,16 @@ int f5hip_cfm_sample_masked(f5hip_dit* m, int32_t n_utt, const int32_t* dur, con
         if (dur[u] <= 0 || dur[u] > 4096) return fail(-1, "dur[%d] = %d out of range", u, dur[u]);
         const int kv = kv_len ? kv_len[u] : dur[u];
         if (kv <= 0 || kv > dur[u]) return fail(-1, "kv_len[%d] = %d out of range (1..%d)", u, kv, dur[u]);
+        // MMDiT text stream: with batch-1 semantics a unit's text tensor is its own tokens (the reference's per-item call pads nothing); with
+        // the padded-batch semantics every item carries the batch's nt positions, fillers included
+        int c_len = nt_max;
+        if (!kv_len) { c_len = 0; while (c_len < nt_max && text[(size_t)u * nt_max + c_len] != -1) c_len++; }
         seqs.push_back({dur[u], kv, f0, u, 0, 0, 0});
+        seqs.back().c_len = std::max(c_len, 1);
         m->h_seq_len.push_back(dur[u]);
         if (use_cfg) {
             seqs.push_back({dur[u], kv, f0, u, 1, 1, 1});
+            seqs.back().c_len = std::max(c_len, 1);
             m->h_seq_len.push_back(dur[u]);
         }
         f0 += dur[u];

@@ -57,6 +57,26 @@ E2TTS_BASE = UNetTArch()
 E2TTS_SMALL = UNetTArch(dim=768, depth=20, heads=12)
 
 
+@dataclass(frozen=True)
+class MMDiTArch:
+    """MMDiT.__init__ arguments (F/model/backbones/mmdit.py:84-95): dual-stream blocks over the audio frames and the text tokens, joint
+    attention, the last block context-pre-only; the text is embedded at `dim` (no ConvNeXt).  No YAML of the reference uses it."""
+    dim: int = 512
+    depth: int = 16
+    heads: int = 16
+    ff_mult: int = 2
+    mel_dim: int = 100
+    text_num_embeds: int = 256
+
+    @property
+    def text_dim(self):
+        return self.dim
+
+    @property
+    def conv_layers(self):
+        return 0
+
+
 def _i32(a):
     return np.ascontiguousarray(np.asarray(a, dtype=np.int32))
 
@@ -68,7 +88,7 @@ def _ptr(t):
 
 
 class F5HipModel:
-    def __init__(self, arch: DiTArch | UNetTArch, state_dict: dict, vocab_char_map: dict | None = None, gemm_planes: int = 3,
+    def __init__(self, arch: DiTArch | UNetTArch | MMDiTArch, state_dict: dict, vocab_char_map: dict | None = None, gemm_planes: int = 3,
                  device: str | torch.device = "cuda:0", mel_spec_type: str = "vocos", odeint_kwargs: dict | None = None):
         # odeint_kwargs: CFM's constructor argument (F/model/cfm.py:37-41), dict(method="euler") by default; "midpoint" is the other
         # fixed-grid solver the reference names.  Adaptive torchdiffeq solvers are not offered.
@@ -87,7 +107,7 @@ class F5HipModel:
             raise _lib.F5HipError("F5HipModel needs a HIP device (no CPU fallback)")
         torch.cuda.set_device(self.device)
         cfg = _lib.DitConfig(arch.dim, arch.depth, arch.heads, arch.ff_mult, arch.text_dim, arch.conv_layers,
-                             arch.mel_dim, arch.text_num_embeds, gemm_planes, 1 if isinstance(arch, UNetTArch) else 0)
+                             arch.mel_dim, arch.text_num_embeds, gemm_planes, 1 if isinstance(arch, UNetTArch) else (2 if isinstance(arch, MMDiTArch) else 0))
         self._h = self._lib.f5hip_dit_create(C.byref(cfg))
         if not self._h:
             raise _lib.F5HipError("f5hip_dit_create: " + self._lib.f5hip_last_error().decode())
