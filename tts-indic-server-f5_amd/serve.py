@@ -262,7 +262,9 @@ class ShardedSampler:
     samples its share on its own GPU with its own replica of the weights, and the mels come back to rank 0 in unit order.
     There is no collective inside the ODE loop: one job broadcast (tokens, frame counts, the reference mels of the voices in the
     batch: 188 KB per voice) and one gather per batch, RCCL over xGMI when the process group's backend is "nccl".
-    Ranks > 0 run `rank_worker_loop(local_model)`; `close()` on rank 0 releases them."""
+    Ranks > 0 run `rank_worker_loop(local_model)`; `close()` on rank 0 releases them.
+    Noise: every rank draws the noise of ITS units from its own generator (like the reference's per-call `torch.randn`, unseeded in
+    `infer_batch_process`), so an unseeded result is not reproducible across world sizes; pass `seed=` in the knobs for that."""
 
     def __init__(self, local_model, device=None):
         import torch
