@@ -293,6 +293,14 @@ def run_rank(args):
                          "attn_tflops": round(attn_tf, 1), "attn_frac": round(attn_tf / PEAK_BF16_TFLOPS, 4)},
             "kernel_ms": prof,
         }
+        if bigv is not None and not args.ragged and prof["vocos"]["total_ms"] > 0:
+            # north_star: "achieved HBM GB/s on vocoder conv".  Algorithmic bytes = the ideal fused fp32 activation traffic of one 936-frame
+            # BigVGAN v2 decode (9.1 GB) x the utterances rank 0 decoded, over the decode's HIP-event time.
+            v_gbs = 9.1 * B / (prof["vocos"]["total_ms"] * 1e-3)
+            result["vocoder_roofline"] = {"bound": "hbm", "kernel": "BigVGAN v2 decode: conv5 / implicit-GEMM convolutions + aa_snake2 + block mean + conv_post",
+                                          "achieved": round(v_gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(v_gbs / 8000.0, 4),
+                                          "algorithmic_bytes_per_utterance": 9.1e9, "utterances": B, "decode_ms": prof["vocos"]["total_ms"],
+                                          "conv_precision": {1: "bf16", 2: "split bf16 (parity mode)", 3: "fp16 (fast mode, outside the 1e-4 waveform bound)"}[args.vocoder_planes]}
         if not args.no_cpu_baseline and world == 1 and B == 1 and bigv is None and not args.ragged:
             n_threads = min(len(os.sched_getaffinity(0)), 32)
             result["cpu_baseline"] = cpu_baseline(sd, vsd, cond0.cpu()[None], torch.cat([ref_ids0, gen_ids[0]]).cpu()[None], y0[0].cpu()[None], n_threads)
