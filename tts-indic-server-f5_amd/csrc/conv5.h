@@ -32,9 +32,11 @@ F5_DEVICE int c5_off(int row, int c16) {
     else return row * 64 + ((c16 ^ ((row >> 2) & 3)) << 4);
 }
 
-template <int NPL, int ROWB, int NB>
+// RBW = 32-row blocks per consumer wave: 2 -> 256-row tiles (the BigVGAN stages, whose sequences are multiples of 256 rows), 1 -> 128-row
+// tiles (the DiT's conv_pos_embed: sequences are padded to 128 rows, so a 128-row tile never straddles two of them)
+template <int NPL, int ROWB, int NB, int RBW = 2>
 struct Conv5Cfg {
-    static constexpr int BM = 256, BN = NB * 32, HMAX = 25;
+    static constexpr int BM = 128 * RBW, BN = NB * 32, HMAX = 25;
     static constexpr int CKC = ROWB / 2;                  // channels per chunk
     static constexpr int CPR = ROWB / 16;                 // 16-byte chunks per LDS row
     static constexpr int WST = NPL * BN * ROWB;           // one weight stage (all planes)
@@ -54,9 +56,9 @@ struct Conv5Cfg {
 // ABL = 1 (diagnostics, only reached with GemmArgs::stamps set): s_memtime stamps of wave 0 (consumer) and wave 4 (loader) of every
 // workgroup into p.stamps[block][16]: consumer 0 start, 1 loop begin, 2 loop end, 3 cycles spent at barriers, 4 end;
 // loader 8 start, 9 loop begin, 10 loop end, 11 cycles in the counted waits, 12 at barriers, 13 in window stores, 14 in issue + fetch.
-template <int NPL, int ROWB, int NB, bool F16, int ABL = 0>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(Conv5Cfg<NPL, ROWB, NB>::WAVES_PER_EU, Conv5Cfg<NPL, ROWB, NB>::WAVES_PER_EU))) void conv5_kernel(const GemmArgs p, const int tiles_m, const int taps, const int halo, const int wrows) {
-    using C = Conv5Cfg<NPL, ROWB, NB>;
+template <int NPL, int ROWB, int NB, bool F16, int ABL = 0, int RBW = 2>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(Conv5Cfg<NPL, ROWB, NB, RBW>::WAVES_PER_EU, Conv5Cfg<NPL, ROWB, NB, RBW>::WAVES_PER_EU))) void conv5_kernel(const GemmArgs p, const int tiles_m, const int taps, const int halo, const int wrows) {
+    using C = Conv5Cfg<NPL, ROWB, NB, RBW>;
     constexpr int BM = C::BM, BN = C::BN, NST = C::NST, CKC = C::CKC, CPR = C::CPR, WST = C::WST, PW = C::PW, P_HI = C::P_HI, P_LO = C::P_LO, WV = C::WV;
     constexpr int KS = ROWB / 32;                              // 16-deep MFMA k-substeps per k-step
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -68,7 +70,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(Conv5Cfg<NP
     const int t = (nblk & 7) ? (int)blockIdx.x : ((int)blockIdx.x & 7) * (nblk >> 3) + ((int)blockIdx.x >> 3);
     const int tn = t / tiles_m, tm = t - tn * tiles_m;
     const int m0 = tm * BM, n0 = tn * BN;
-    const int c_pad = p.lda;
+    const int c_pad = p.K / taps;                              // channels per tap in the weight's K layout (== lda for a dense convolution)
+    const int a_col0 = tn * p.conv_group_cols;                 // grouped convolution: column tile = group, its input channels start here
     const int nchunks = c_pad / CKC, nk = nchunks * taps;
     const int dil = p.conv_dil > 1 ? p.conv_dil : 1;
     const int win_plane = wrows * ROWB;                        // bytes of one plane of one window buffer
@@ -83,7 +86,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(Conv5Cfg<NP
         // ------------------------------------------------------------------------------------------------ loader waves
         const int pw = wave - 4, ll = tid - 256;
         const int mine = (PW - pw + 3) >> 2;                   // weight pieces pw, pw + 4, ... of every k-step
-        const int sstart = (m0 / p.seq_pitch) * p.seq_pitch, send = sstart + p.seq_valid;
+        // the tile lies in one sequence (BM divides the sequence pitch / padding): its bounds are those of its first row
+        const int sstart = p.row_seq_start ? p.row_seq_start[m0] : (m0 / p.seq_pitch) * p.seq_pitch;
+        const int send = p.row_seq_start ? p.row_seq_end[m0] : sstart + p.seq_valid;
         const char* wsrc[P_HI];
 #pragma unroll
         for (int j = 0; j < P_HI; j++) {
@@ -136,7 +141,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(Conv5Cfg<NP
                 const int w = rem / CPR, c = rem - w * CPR;
                 const int g = m0 - halo + w;
                 const int gc = min(max(g, sstart), send - 1);   // always a valid row; rows outside the sequence are zeroed at the LDS write
-                v[i] = *reinterpret_cast<const u32x4*>(p.A[NPL == 2 ? pl : 0] + (size_t)gc * p.lda + (size_t)chunk * CKC + c * 8);
+                v[i] = *reinterpret_cast<const u32x4*>(p.A[NPL == 2 ? pl : 0] + (size_t)gc * p.lda + a_col0 + (size_t)chunk * CKC + c * 8);
             }
         };
         auto store_window = [&](int chunk) {
@@ -198,16 +203,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(Conv5Cfg<NP
     const int fr = lane & 31, fh = lane >> 5;
     constexpr int HK = KS / 2;
     static_assert(KS == 2 || KS == 4, "one or two MFMA k-substeps per half k-step");
-    struct Half { bf16x8 a[HK][NPL][2], b[HK][NPL][NB]; };
-    f32x16 acc[2][NB];
+    struct Half { bf16x8 a[HK][NPL][RBW], b[HK][NPL][NB]; };
+    f32x16 acc[RBW][NB];
 #pragma unroll
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < RBW; i++)
 #pragma unroll
         for (int j = 0; j < NB; j++)
 #pragma unroll
             for (int g = 0; g < 16; g++) acc[i][j][g] = 0.0f;
     const int center = p.conv_center;
-    const int row_base = wave * 64 + halo + fr;                  // window row of this lane's first A-fragment row at tap == center
+    const int row_base = wave * (32 * RBW) + halo + fr;          // window row of this lane's first A-fragment row at tap == center
     // fragments of half `h` of the k-step (chunk, tap) whose weight tile sits in stage `stage`
     auto load_half = [&](Half& f, int chunk, int tap, int stage, int h) {
         const char* win = win0 + (chunk & 1) * win_buf;
@@ -219,7 +224,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(Conv5Cfg<NP
 #pragma unroll
             for (int pl = 0; pl < NPL; pl++) {
 #pragma unroll
-                for (int i = 0; i < 2; i++) f.a[q][pl][i] = *reinterpret_cast<const bf16x8*>(win + pl * win_plane + c5_off<ROWB>(wrow + i * 32, c16));
+                for (int i = 0; i < RBW; i++) f.a[q][pl][i] = *reinterpret_cast<const bf16x8*>(win + pl * win_plane + c5_off<ROWB>(wrow + i * 32, c16));
 #pragma unroll
                 for (int j = 0; j < NB; j++) f.b[q][pl][j] = *reinterpret_cast<const bf16x8*>(wst + pl * (BN * ROWB) + c5_off<ROWB>(j * 32 + fr, c16));
             }
@@ -229,7 +234,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(Conv5Cfg<NP
 #pragma unroll
         for (int q = 0; q < HK; q++)
 #pragma unroll
-            for (int i = 0; i < 2; i++)
+            for (int i = 0; i < RBW; i++)
 #pragma unroll
                 for (int j = 0; j < NB; j++) {
                     if constexpr (NPL == 2) {
@@ -263,7 +268,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(Conv5Cfg<NP
         // Issue order inside a half k-step, pinned with sched_group_barrier: one fragment read of the OTHER half behind each of the first
         // MFMAs of this half.  Left alone the scheduler, short of registers, sinks every read back to just in front of its first use (the
         // MFMAs then wait on LDS latency); all reads in one block in front of the MFMAs costs ~150 cycles per half in which no MFMA issues.
-        constexpr int READS = HK * NPL * (2 + NB), MFMAS = HK * 2 * NB * (NPL == 2 ? 3 : 1);
+        constexpr int READS = HK * NPL * (RBW + NB), MFMAS = HK * RBW * NB * (NPL == 2 ? 3 : 1);
         constexpr int PAIRS = READS < MFMAS ? READS : MFMAS;
         auto interleave = [&]() {
     #pragma unroll
@@ -301,15 +306,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(Conv5Cfg<NP
     if constexpr (ABL) ts[2] = C5_NOW();
 
     // ---------------------------------------------------------------------------------------------------- epilogue
-    // accumulator g of block (i, j): row = i * 32 + (g & 3) + 8 * (g >> 2) + 4 * fh, column = j * 32 + fr
+    // accumulator g of block (i, j): row = i * 32 + (g & 3) + 8 * (g >> 2) + 4 * fh, column = j * 32 + fr.
+    // BigVGAN tiles (RBW == 2): v = acc + bias + res -> fp32 rows, nothing else compiled in (these kernels sit at ~240 registers).
+    // General epilogue (GEN: the 128-row grouped variant): v = act(acc + bias) + res -> fp32 rows and / or split-bf16 planes; grouped
+    // convolution (p.group_w > 0: the column tile is a group padded to BN columns): real column = group * group_w + local column,
+    // local columns >= group_w are padding.
+    constexpr bool GEN = RBW == 1;
 #pragma unroll
     for (int j = 0; j < NB; j++) {
-        const int col = n0 + j * 32 + fr;
-        if (col >= p.N) continue;
-        const float b = p.bias ? p.bias[col] : 0.0f;
+        const int lc = j * 32 + fr;
+        const int col = GEN && p.group_w > 0 ? tn * p.group_w + lc : n0 + lc;
+        if (GEN && p.group_w > 0 ? lc >= p.group_w : col >= p.N) continue;
+        const float b = p.bias ? p.bias[n0 + lc] : 0.0f;
 #pragma unroll
-        for (int i = 0; i < 2; i++) {
-            const int rbase = m0 + wave * 64 + i * 32 + 4 * fh;
+        for (int i = 0; i < RBW; i++) {
+            const int rbase = m0 + wave * (32 * RBW) + i * 32 + 4 * fh;
             // residual loads in groups of GR rows: all 16 at once on the wide tiles (one workgroup per CU: memory-level parallelism),
             // 4 at a time on the narrow ones (128-register budget; the second workgroup on the CU supplies the overlap)
             constexpr int GR = NB <= 2 ? 4 : 16;
@@ -322,9 +333,23 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(Conv5Cfg<NP
                 }
 #pragma unroll
                 for (int g = 0; g < GR; g++) {
+                    const size_t row = (size_t)(rbase + ((g0 + g) & 3) + 8 * ((g0 + g) >> 2));
                     float v = acc[i][j][g0 + g] + b;
+                    if constexpr (GEN) {
+                        if (p.act == ACT_MISH) v = apply_act(v, ACT_MISH);
+                    }
                     if (p.res) v += r[g];
-                    p.out_f32[(size_t)(rbase + ((g0 + g) & 3) + 8 * ((g0 + g) >> 2)) * p.ldo + col] = v;
+                    if constexpr (GEN) {
+                        if (p.out_f32) p.out_f32[row * p.ldo + col] = v;
+                        if (p.out_hi) {
+                            __bf16 hi, lo;
+                            split_bf16(v, hi, lo);
+                            p.out_hi[row * p.ldob + col] = hi;
+                            if (p.out_lo) p.out_lo[row * p.ldob + col] = lo;
+                        }
+                    } else {
+                        p.out_f32[row * p.ldo + col] = v;
+                    }
                 }
             }
         }
@@ -340,23 +365,35 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(Conv5Cfg<NP
 #undef C5_NOW
 }
 
-template <int NPL, int ROWB, int NB, bool F16, int ABL = 0>
+template <int NPL, int ROWB, int NB, bool F16, int ABL = 0, int RBW = 2>
 static hipError_t launch_conv5_t(const GemmArgs& a, int n_pad, int taps, hipStream_t st) {
-    using C = Conv5Cfg<NPL, ROWB, NB>;
+    using C = Conv5Cfg<NPL, ROWB, NB, RBW>;
     const int dil = a.conv_dil > 1 ? a.conv_dil : 1;
     const int halo = a.conv_center * dil;
-    const int nchunks = a.lda / C::CKC;
+    const int nchunks = (a.K / taps) / C::CKC;
     const int lds = C::lds_bytes(halo, nchunks);
     static unsigned attr_mask = 0;
-    if (hipError_t e = f5_set_lds_attr(reinterpret_cast<const void*>(&conv5_kernel<NPL, ROWB, NB, F16, ABL>), 160 * 1024, attr_mask); e != hipSuccess) return e;
+    if (hipError_t e = f5_set_lds_attr(reinterpret_cast<const void*>(&conv5_kernel<NPL, ROWB, NB, F16, ABL, RBW>), 160 * 1024, attr_mask); e != hipSuccess) return e;
     const int tiles_m = a.M / C::BM, tiles_n = n_pad / C::BN;
-    hipLaunchKernelGGL((conv5_kernel<NPL, ROWB, NB, F16, ABL>), dim3(tiles_m * tiles_n), dim3(512), lds, st, a, tiles_m, taps, halo, C::win_rows(halo));
+    hipLaunchKernelGGL((conv5_kernel<NPL, ROWB, NB, F16, ABL, RBW>), dim3(tiles_m * tiles_n), dim3(512), lds, st, a, tiles_m, taps, halo, C::win_rows(halo));
     return hipGetLastError();
 }
 
 // prec: 1 = bf16, 2 = split bf16, 3 = fp16 (one plane).  hipErrorInvalidValue: shape not covered (the caller falls back to gemm.h).
 static hipError_t launch_conv5(int prec, const GemmArgs& a, int n_pad, hipStream_t st) {
-    if (a.row_seq_start || a.conv_group_cols || a.group_w || a.act || a.mul || a.row_keep || a.out_hi || !a.out_f32) return hipErrorInvalidValue;
+    if (a.conv_group_cols > 0) {
+        // grouped Conv1d of the DiT's ConvPositionEmbedding (k = 31, 16 groups padded to 64 columns / 64 channels each, split bf16, Mish,
+        // optional fp32 residual, fp32 rows or split-bf16 planes out): 128-row tiles, one column tile per group.  The sequence bounds
+        // come from the tile's first row, so every sequence must start at a multiple of 128 rows (the packed layout pads to that).
+        if (prec != 2 || a.group_w != a.conv_group_cols || a.group_w > 64 || n_pad % 64 || a.mul || a.row_keep || !a.row_seq_start || !a.row_seq_end ||
+            (a.act != ACT_NONE && a.act != ACT_MISH) ||
+            (!a.out_f32 && !a.out_hi) || a.M % 128 || a.conv_center <= 0 || a.conv_center > 25 || (a.conv_dil > 1))
+            return hipErrorInvalidValue;
+        const int taps = 2 * a.conv_center + 1;
+        if (a.K % taps || a.K / taps != 64) return hipErrorInvalidValue;
+        return launch_conv5_t<2, 64, 2, false, 0, 1>(a, n_pad, taps, st);
+    }
+    if (a.row_seq_start || a.group_w || a.act || a.mul || a.row_keep || a.out_hi || !a.out_f32) return hipErrorInvalidValue;
     if (a.lda <= 0 || a.K % a.lda) return hipErrorInvalidValue;
     const int taps = a.K / a.lda;
     const int dil = a.conv_dil > 1 ? a.conv_dil : 1;

@@ -983,6 +983,21 @@ static int forward_mmdit_layers(f5hip_dit* m, int ti, int n_blocks, hipStream_t 
     return 0;
 }
 
+// One grouped convolution of ConvPositionEmbedding: the sliding-window kernel (conv5.h, 128-row tiles, one column tile per group) for the
+// DiT and MMDiT layouts, the implicit GEMM of gemm.h otherwise (UNetT: the time-token row at the head of every sequence has an empty
+// window of its own, which a per-tile bound cannot express) or with F5HIP_CONV5=0.
+static int run_pos_conv(f5hip_dit* m, GemmArgs& g, const PackedW& W, hipStream_t st) {
+    static const int use_conv5 = getenv("F5HIP_CONV5") ? atoi(getenv("F5HIP_CONV5")) : 1;
+    if (use_conv5 && m->arch != 1 && m->nsplit == 2 && !W.f16) {
+        prof_begin(PROF_GEMM, st);
+        const hipError_t e = f5_launch_conv5(2, g, W.n_pad, st);
+        prof_end(PROF_GEMM, st);
+        if (e == hipSuccess) { g_counters[4]++; return 0; }
+        if (e != hipErrorInvalidValue) return fail(-7, "conv5 launch: %s", hipGetErrorString(e));
+    }
+    return run_gemm(m, g, W, EPI_GENERIC, true, 64, st);
+}
+
 static int forward_step(f5hip_dit* m, int ti, int n_blocks, hipStream_t st) {
     const f5hip_dit_config& c = m->cfg;
     const int D = c.dim, F = c.ff_mult * D, M = m->M;
@@ -997,12 +1012,12 @@ static int forward_step(f5hip_dit* m, int ti, int n_blocks, hipStream_t st) {
     c1.conv_kpt = 2; c1.conv_center = 15; c1.conv_group_cols = m->gw; c1.row_seq_start = m->d_row_start; c1.row_seq_end = m->d_row_end;
     c1.group_w = m->gw; c1.N = 16 * 64;
     c1.act = ACT_MISH; c1.out_hi = m->c1.hi; c1.out_lo = m->c1.lo; c1.ldob = D;
-    CK(run_gemm(m, c1, m->conv1, EPI_GENERIC, true, 64, st));
+    CK(run_pos_conv(m, c1, m->conv1, st));
     GemmArgs c2 = gemm_base(m->c1, D, m->conv2, M);
     c2.conv_kpt = 2; c2.conv_center = 15; c2.conv_group_cols = m->gw; c2.row_seq_start = m->d_row_start; c2.row_seq_end = m->d_row_end;
     c2.group_w = m->gw; c2.N = 16 * 64;
     c2.act = ACT_MISH; c2.res = m->h0; c2.ldres = D; c2.out_f32 = m->h; c2.ldo = D;
-    CK(run_gemm(m, c2, m->conv2, EPI_GENERIC, true, 64, st));
+    CK(run_pos_conv(m, c2, m->conv2, st));
 
     const int nb = n_blocks < 0 ? c.depth : n_blocks;
     if (m->arch == 1) return forward_unett_layers(m, ti, n_blocks, st);
