@@ -39,7 +39,8 @@ struct f5hip_dit {
     StreamKWs sk;         // stream-K partial-tile slots + flags (experiments/gemm4.h), owned by the handle: launches of one handle are stream-ordered
 #endif
     bool blk_f16 = false; // gemm_planes == 3: transformer-block GEMMs (QKV, out, FF1, FF2) take one fp16 plane per operand
-    // fused LayerNorm in front of the QKV / FF1 GEMMs (gemm5 LNF kernels): per-handle arrival counters and a host-visible time-out flag
+    // LayerNorm fused behind the residual GEMMs (gemm5 LNE kernels: experiments builds only, measured slower): per-handle arrival
+    // counters and a host-visible time-out flag
     unsigned* ln_sync = nullptr;   // [16] row slabs, monotonic
     unsigned ln_epoch = 0;         // fused launches since the counters were zeroed (every one adds 16 arrivals to each of its slabs)
     int ln_slabs = 0;              // row slabs of those launches: a launch with another count zeroes the counters first (stream-ordered)
