@@ -272,7 +272,8 @@ def run_rank(args):
         attn_fl = sum(attn_algorithmic_flops(n=f) for f in my_frames)
         attn_tf = attn_fl / (att["total_ms"] * 1e-3) / 1e12 if att["total_ms"] > 0 else 0.0
         traffic, traffic_src = pmc_traffic() if (args.gemm_planes == 3 and B == 1 and not args.ragged) else (None, None)
-        par = f"utterance-sharded x{n_gpus}, RCCL broadcast of ref latents" + (", LPT dealing + RCCL gather of the waveforms to rank 0" if args.mode == "strong" else "")
+        coll = "RCCL" if backend == "nccl" else backend     # (gloo only when rehearsing the N > 1 path on a box with fewer GPUs than ranks)
+        par = f"utterance-sharded x{n_gpus}, {coll} broadcast of ref latents" + (f", LPT dealing + {coll} gather of the waveforms to rank 0" if args.mode == "strong" else "")
         result = {
             "metric": "mel-frames/sec + RTF, F5-TTS-Base 32-NFE, 10s utterance", "value": round(value, 1),
             "unit": "mel-frames/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
