@@ -117,6 +117,26 @@ def test_bench_launcher_spawns_one_rank_per_gpu():
     assert d["n_gpus"] == 2 and d["value"] == 3.0 and d["steps"] == 3 and d["mode"] == "strong"   # sum over ranks of (rank + 1)
 
 
+def test_bench_under_torch_distributed_run():
+    """The driver's own N > 1 invocation: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P
+    bench.py --gpus N ...` -- bench.py must join the group torchrun made (no second spawn) and rank 0 alone prints the JSON line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env["F5HIP_BENCH_FAKE"] = "1"
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                            # one line, from rank 0
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] == 3.0 and d["steps"] == 3
+
+
 def test_strong_mode_sharding_covers_every_unit_once():
     from tts_indic_server_f5_amd.sharding import shard_units, unit_cost
     frames = [1404] * 64
