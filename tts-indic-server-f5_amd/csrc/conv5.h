@@ -50,7 +50,11 @@ struct Conv5Cfg {
     static constexpr int NST = WST >= 16384 ? 5 : 3;   // (the narrow tiles have 3-33 k-steps and want LDS for a second workgroup instead)
     static constexpr int WAVES_PER_EU = NB <= 2 ? 4 : 2;   // narrow tiles: 64 accumulator registers, two workgroups per CU
     static int win_rows(int halo) { return (BM + 2 * halo + 7) & ~7; }
-    static int lds_bytes(int halo, int nchunks) { return (nchunks > 1 ? 2 : 1) * win_rows(halo) * ROWB * NPL + NST * WST; }
+    // Narrow 256-row tiles keep ONE window buffer even with several channel chunks (the loaders rewrite it between two extra barriers at
+    // a chunk boundary): two workgroups then fit a CU, and the other one covers the gap.  Every other tile double-buffers the window.
+    static constexpr bool SINGLE_WIN = NB <= 2 && RBW == 2;
+    static int win_bufs(int nchunks) { return nchunks > 1 && !SINGLE_WIN ? 2 : 1; }
+    static int lds_bytes(int halo, int nchunks) { return win_bufs(nchunks) * win_rows(halo) * ROWB * NPL + NST * WST; }
 };
 
 // ABL = 1 (diagnostics, only reached with GemmArgs::stamps set): s_memtime stamps of wave 0 (consumer) and wave 4 (loader) of every
@@ -77,7 +81,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(Conv5Cfg<NP
     const int win_plane = wrows * ROWB;                        // bytes of one plane of one window buffer
     const int win_buf = win_plane * NPL;
     char* const win0 = smem;
-    char* const wst0 = smem + (nchunks > 1 ? 2 : 1) * win_buf;
+    constexpr bool SINGLE_WIN = C::SINGLE_WIN;
+    const int wsel = SINGLE_WIN ? 0 : 1;                       // window of chunk c lives in buffer c & wsel
+    char* const wst0 = smem + (nchunks > 1 && !SINGLE_WIN ? 2 : 1) * win_buf;
     unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define C5_NOW() ((unsigned long long)__builtin_amdgcn_s_memtime())
     if constexpr (ABL) ts[0] = C5_NOW();
@@ -145,7 +151,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(Conv5Cfg<NP
             }
         };
         auto store_window = [&](int chunk) {
-            char* dstb = win0 + (chunk & 1) * win_buf;
+            char* dstb = win0 + (chunk & wsel) * win_buf;
 #pragma unroll
             for (int i = 0; i < WV; i++) {
                 const int idx = ll + 256 * i;
@@ -175,7 +181,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(Conv5Cfg<NP
             if constexpr (ABL) t2 = C5_NOW();
             const int chunk = kt / taps, tap = kt - chunk * taps;
             const bool more = chunk + 1 < nchunks;
-            if (more && tap == taps - 1) store_window(chunk + 1);   // BEFORE the next issue: the compiler's wait for v[] then covers only older groups
+            if constexpr (SINGLE_WIN) {
+                // behind B_kt of a chunk's FIRST tap every consumer is done with the chunk before: write this chunk's window (fetched a chunk
+                // ago) over it, then a second barrier releases the consumers
+                if (tap == 0 && chunk > 0) {
+                    store_window(chunk);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();                // B'_kt
+                }
+            } else {
+                if (more && tap == taps - 1) store_window(chunk + 1);   // BEFORE the next issue: the compiler's wait for v[] then covers only older groups
+            }
             if constexpr (ABL) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); t3 = C5_NOW(); }
             if (kt >= 1 && kt - 1 + NST < nk) issue_w(kt - 1 + NST);
             if (more && tap == 0) {
@@ -215,7 +231,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(Conv5Cfg<NP
     const int row_base = wave * (32 * RBW) + halo + fr;          // window row of this lane's first A-fragment row at tap == center
     // fragments of half `h` of the k-step (chunk, tap) whose weight tile sits in stage `stage`
     auto load_half = [&](Half& f, int chunk, int tap, int stage, int h) {
-        const char* win = win0 + (chunk & 1) * win_buf;
+        const char* win = win0 + (chunk & wsel) * win_buf;
         const char* wst = wst0 + stage * WST;
         const int wrow = row_base + (tap - center) * dil;
 #pragma unroll
@@ -251,6 +267,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(Conv5Cfg<NP
         Half h;
         for (int kt = 0; kt < nk; kt++) {
             __builtin_amdgcn_s_barrier();                        // B_kt
+            if constexpr (SINGLE_WIN) {
+                if (tap == 0 && chunk > 0) __builtin_amdgcn_s_barrier();   // B'_kt: the loaders have rewritten the (single) window buffer
+            }
             load_half(h, chunk, tap, stage, 0);
             mfma_half(h);
             load_half(h, chunk, tap, stage, 1);
