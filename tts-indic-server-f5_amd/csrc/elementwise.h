@@ -98,6 +98,17 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* x, int ldx
     }
 }
 
+// fp32 [rows][C] -> ONE fp16 plane [rows][ldo] at column col0 (saturating; the operand of a PREC_F16 GEMM), 4 columns per lane
+__global__ __launch_bounds__(256) void cast_rows_f16_kernel(const float* x, int ldx, int C, int M, __bf16* out, int ldo, int col0) {
+    const int row = blockIdx.x;
+    if (row >= M) return;
+    for (int c = threadIdx.x * 4; c < C; c += 1024) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + (size_t)row * ldx + c);
+        const float y[4] = {v[0], v[1], v[2], v[3]};
+        store_f16x4(out + (size_t)row * ldo + col0 + c, y);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // CFG combine + Euler step (F/model/cfm.py:176 and torchdiffeq fixed-grid Euler):
 //   v = p + (p - p0) * cfg ;  x += dt * v

@@ -39,6 +39,7 @@ struct f5hip_dit {
     StreamKWs sk;         // stream-K partial-tile slots + flags (experiments/gemm4.h), owned by the handle: launches of one handle are stream-ordered
 #endif
     bool blk_f16 = false; // gemm_planes == 3: transformer-block GEMMs (QKV, out, FF1, FF2) take one fp16 plane per operand
+    bool skip_f16 = false; // UNetT (experiment, F5HIP_UNETT_SKIP_F16=1): the U-skip projections too
     // LayerNorm fused behind the residual GEMMs (gemm5 LNE kernels: experiments builds only, measured slower): per-handle arrival
     // counters and a host-visible time-out flag
     unsigned* ln_sync = nullptr;   // [16] row slabs, monotonic
@@ -105,6 +106,7 @@ f5hip_dit* f5hip_dit_create(const f5hip_dit_config* cfg) {
     // both backbones: against the reference's own digests mixed mode measures 3.1e-4 rms (F5-Base, 32 NFE) and 4.9e-4 (E2-Base, N = 2340,
     // 64 NFE) of the 1e-3 bound; the U-skip projections, the final norm + proj_out and the input embedding stay split bf16
     m->blk_f16 = cfg->gemm_planes == 3;
+    m->skip_f16 = m->blk_f16 && cfg->arch == 1 && getenv("F5HIP_UNETT_SKIP_F16") && atoi(getenv("F5HIP_UNETT_SKIP_F16")) == 1;
     m->arch = cfg->arch;
     if (hipMalloc((void**)&m->ln_sync, 16 * sizeof(unsigned)) != hipSuccess || hipMemset(m->ln_sync, 0, 16 * sizeof(unsigned)) != hipSuccess ||
         hipHostMalloc((void**)&m->ln_err, sizeof(int), hipHostMallocMapped) != hipSuccess) {
@@ -331,7 +333,7 @@ int f5hip_dit_finalize(f5hip_dit* m) {
             if (upload_f32(&m->g_attn[l], ga->data(), D) || upload_f32(&m->g_ff[l], gf->data(), D)) return -4;
             if (l >= c.depth / 2) {
                 GETP(ws, p + "0.weight", (int64_t)D * 2 * D);
-                if (pack_linear(m->wskip[l], ws->data(), D, 2 * D, 2 * D, nullptr)) return -4;
+                if (pack_linear(m->wskip[l], ws->data(), D, 2 * D, 2 * D, nullptr, 128, m->skip_f16)) return -4;
             }
         }
     }
@@ -831,16 +833,18 @@ static int forward_unett_layers(f5hip_dit* m, int ti, int n_blocks, hipStream_t 
     for (int l = 0; l < nb; l++) {
         if (l < c.depth / 2) {
             prof_begin(PROF_OTHER, st);
-            hipLaunchKernelGGL(split_rows_kernel, dim3(M), dim3(256), 0, st, m->h, D, D, M, (const int*)nullptr, m->skipbuf[l].hi, m->skipbuf[l].lo, D, 0);
+            if (m->skip_f16) hipLaunchKernelGGL(cast_rows_f16_kernel, dim3(M), dim3(256), 0, st, m->h, D, D, M, m->skipbuf[l].hi, D, 0);
+            else hipLaunchKernelGGL(split_rows_kernel, dim3(M), dim3(256), 0, st, m->h, D, D, M, (const int*)nullptr, m->skipbuf[l].hi, m->skipbuf[l].lo, D, 0);
             prof_end(PROF_OTHER, st);
             CKL("skip save");
         } else {
             const Plane2& sk = m->skipbuf[c.depth - 1 - l];
             prof_begin(PROF_OTHER, st);
-            hipLaunchKernelGGL(split_rows_kernel, dim3(M), dim3(256), 0, st, m->h, D, D, M, (const int*)nullptr, m->ff.hi, m->ff.lo, 2 * D, 0);
+            if (m->skip_f16) hipLaunchKernelGGL(cast_rows_f16_kernel, dim3(M), dim3(256), 0, st, m->h, D, D, M, m->ff.hi, 2 * D, 0);
+            else hipLaunchKernelGGL(split_rows_kernel, dim3(M), dim3(256), 0, st, m->h, D, D, M, (const int*)nullptr, m->ff.hi, m->ff.lo, 2 * D, 0);
             CKL("skip concat x");
             if (hipMemcpy2DAsync(m->ff.hi + D, (size_t)2 * D * 2, sk.hi, (size_t)D * 2, (size_t)D * 2, M, hipMemcpyDeviceToDevice, st) != hipSuccess ||
-                hipMemcpy2DAsync(m->ff.lo + D, (size_t)2 * D * 2, sk.lo, (size_t)D * 2, (size_t)D * 2, M, hipMemcpyDeviceToDevice, st) != hipSuccess)
+                (!m->skip_f16 && hipMemcpy2DAsync(m->ff.lo + D, (size_t)2 * D * 2, sk.lo, (size_t)D * 2, (size_t)D * 2, M, hipMemcpyDeviceToDevice, st) != hipSuccess))
                 return fail(-6, "skip concat copy");
             prof_end(PROF_OTHER, st);
             GemmArgs sp = gemm_base(m->ff, 2 * D, m->wskip[l], M);
