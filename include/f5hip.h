@@ -123,8 +123,9 @@ int f5hip_op_gemm(int32_t M, int32_t N, int32_t K, const float* a_dev, const flo
                   int32_t act, const float* mul_dev, const float* res_dev, const uint8_t* row_keep_host, float* out_dev,
                   uint16_t* out16_dev, int32_t w_copies, int32_t iters, double* avg_us, void* stream);
 /* f5hip_op_qkv: fused to_q | to_k | to_v projection with its epilogue: bias, rotary embedding on channels 0..63 (head 0, interleaved
- *   pairs) of q and k, q / 8, V transposed (F/model/modules.py:409-426).  a_dev [M][D], w_dev [3 D][D], bias_dev [3 D], row_pos host
- *   int32 [M] (rotary position of every row, 0..4096); outputs bf16: qk_dev [ceil128(M)][2 D], vt_dev [D][ceil128(M)]. */
+ *   pairs) of q and k, q * log2(e) / 8 (the attention kernel's scores are base-2 exponents), V transposed (F/model/modules.py:409-426).  a_dev [M][D], w_dev [3 D][D], bias_dev [3 D], row_pos host
+ *   int32 [M] (rotary position of every row, 0..4096); outputs bf16: qk_dev [ceil128(M)][2 D], vt_dev [D][ceil128(M)] with the tokens of
+ *   every aligned group of 16 in the order 0-3, 8-11, 4-7, 12-15 (the order the attention kernel's PV fragments read them in). */
 int f5hip_op_qkv(int32_t M, int32_t D, const float* a_dev, const float* w_dev, const float* bias_dev, const int32_t* row_pos,
                  int32_t prec, uint16_t* qk_dev, uint16_t* vt_dev, int32_t iters, double* avg_us, void* stream);
 /* f5hip_op_attention: softmax(q k^T / 8 + key-padding mask) v per (sequence, head), head dim 64 -- F.scaled_dot_product_attention with the

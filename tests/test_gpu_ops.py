@@ -4,6 +4,7 @@ split-bf16 rounding of the inputs), so the tolerance only has to cover the fp32 
 Shapes are the transformer-block GEMMs of F5-TTS-Base at the BASELINE configs (M = 2816 rows = one 10 s utterance with both CFG
 branches; F/model/modules.py:324-328,409-447) plus ragged / partial-tile / short-K edge cases."""
 import ctypes as C
+import math
 
 import pytest
 import torch
@@ -11,6 +12,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 DEV = "cuda:0"
+Q_SCALE = 0.125 * math.log2(math.e)   # csrc/common.h F5_Q_SCALE: softmax scale 1/8 and log2(e), folded into q by the QKV epilogue
 
 
 def _counter(name):
@@ -134,7 +136,7 @@ def test_gemm_f16_output_saturates():
 @pytest.mark.parametrize("M,D,prec", [(2816, 1024, 3), (1404, 1024, 3), (1536, 768, 3), (2816, 1024, 2), (300, 256, 2)])
 def test_qkv_unit_op(M, D, prec):
     """Fused QKV projection + epilogue against a reference that applies x-transformers' interleaved rotary embedding to channels
-    0..63 of q and k (head 0 only: F/model/modules.py:414-426), scales q by 1/8 and rounds to bf16 like the kernel's outputs."""
+    0..63 of q and k (head 0 only: F/model/modules.py:414-426), scales q by log2(e) / 8 (the attention kernel works in base-2 exponents) and rounds to bf16 like the kernel's outputs."""
     from oracle import dit_oracle as O
     from tts_indic_server_f5_amd import ops
     g = torch.Generator().manual_seed(M + D + prec)
@@ -147,7 +149,7 @@ def test_qkv_unit_op(M, D, prec):
     freqs = O.rotary_freqs(1405, 64)[0][pos]           # [M, 64]
     q[:, :64] = O.apply_rotary(q[None, :, :64], freqs[None])[0]
     k[:, :64] = O.apply_rotary(k[None, :, :64], freqs[None])[0]
-    q = q * 0.125
+    q = q * Q_SCALE
     _reset_counters()
     gq, gk, gv, _ = ops.qkv(a.to(DEV), w.to(DEV), bias, pos.numpy(), prec=prec)
     if prec == 3 and M == 2816:
@@ -180,19 +182,27 @@ def test_layernorm_unit_op(rms):
 
 
 @pytest.mark.parametrize("impl", [3])
-@pytest.mark.parametrize("lens,kv,heads", [((1404, 1404), None, 16), ((300, 50, 257), (300, 41, 200), 4), ((748,), None, 12), ((64,), (1,), 2),
-                                           ((2341, 2341), None, 16)])
-def test_attention_unit_op(impl, lens, kv, heads):
-    """Attention kernel alone vs fp64 softmax attention on the bf16-rounded operands (q after the 1/8 scale), incl. the key-padding mask
-    (F/model/modules.py:429-434), ragged sequences, tiles that overhang a sequence, and the C2 / C1 / C5 shapes."""
+@pytest.mark.parametrize("lens,kv,heads,k_gain", [((1404, 1404), None, 16, 1.0), ((300, 50, 257), (300, 41, 200), 4, 1.0), ((748,), None, 12, 1.0),
+                                                  ((64,), (1,), 2, 1.0), ((2341, 2341), None, 16, 1.0), ((33,), (33,), 2, 1.0), ((97, 160), (40, 129), 2, 1.0),
+                                                  ((1404, 300), (1404, 290), 4, 12.0), ((200,), None, 2, 40.0)])
+def test_attention_unit_op(impl, lens, kv, heads, k_gain):
+    """Attention kernel alone vs fp64 softmax attention on the bf16-rounded operands (q after the log2(e) / 8 scale, undone in fp64), incl. the key-padding mask
+    (F/model/modules.py:429-434), ragged sequences, tiles that overhang a sequence, key counts that end inside either half of a 64-key tile,
+    and the C2 / C1 / C5 shapes.  k_gain > 1 multiplies the keys from position 40 on: logits tens to hundreds of nats above each query's
+    maximum over its first 32 keys, which is what sends a workgroup of attn3 from its fixed-offset fast loop to the running-maximum redo."""
     from tts_indic_server_f5_amd import ops
     g = torch.Generator().manual_seed(sum(lens) + heads)
     n, D = sum(lens), 64 * heads
     q = torch.randn(n, D, generator=g) * 1.5
     k = torch.randn(n, D, generator=g) * 1.5
     v = torch.randn(n, D, generator=g)
+    if k_gain != 1.0:
+        o = 0
+        for L in lens:
+            k[o + 40:o + L] *= k_gain
+            o += L
     out, _ = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), lens, kv, heads=heads, impl=impl)
-    qb, kb, vb = (q * 0.125).bfloat16().double(), k.bfloat16().double(), v.bfloat16().double()
+    qb, kb, vb = (q * Q_SCALE).bfloat16().double() * math.log(2.0), k.bfloat16().double(), v.bfloat16().double()
     o, refs = 0, []
     for i, L in enumerate(lens):
         kl = L if kv is None else kv[i]
@@ -266,7 +276,7 @@ def test_joint_attention_vs_torch(x_len, c_len, x_kv):
     worst = 0.0
     for i, (n, nt) in enumerate(zip(x_len, c_len)):
         sel = torch.cat([torch.arange(ox, ox + n), torch.arange(oc, oc + nt)])
-        qq = bf(q[sel] * 0.125).view(n + nt, heads, 64).transpose(0, 1)
+        qq = (bf(q[sel] * Q_SCALE) * math.log(2.0)).view(n + nt, heads, 64).transpose(0, 1)
         kk = bf(k[sel]).view(n + nt, heads, 64).transpose(0, 1)
         vv = bf(v[sel]).view(n + nt, heads, 64).transpose(0, 1)
         s = qq @ kk.transpose(1, 2)

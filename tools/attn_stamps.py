@@ -9,9 +9,9 @@ fn = L.f5hip_debug_attn_stamps
 fn.restype = C.c_int
 fn.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
 torch.cuda.init()
-for n in (1404, 2816):
-    out = (C.c_uint64 * 4)(); us = C.c_double(0)
-    rc = fn(n, 16, 20, out, C.byref(us))
+for n, heads in ((748, 12), (1404, 16), (2816, 16)):
+    out = (C.c_uint64 * 6)(); us = C.c_double(0)
+    rc = fn(n, heads, 20, out, C.byref(us))
     if rc: print("ERR", L.f5hip_last_error()); continue
     nkt = max(1, out[3])
-    print(f"N={n} heads=16: kernel {us.value:7.1f} us | per KV tile (wave 0): ring wait+barrier {out[0] // nkt:5d}  QK issue {out[1] // nkt:5d}  softmax+PV {out[2] // nkt:5d} cycles  ({nkt} tiles)", flush=True)
+    print(f"N={n} heads={heads}: kernel {us.value:7.1f} us | per KV tile (wave 0): landed-wait {out[5] // nkt:5d}  barrier {out[4] // nkt:5d}  DMA issue {out[0] // nkt:5d}  half 0 {out[1] // nkt:5d}  half 1 {out[2] // nkt:5d} (s_memtime ticks)  ({nkt} tiles)", flush=True)

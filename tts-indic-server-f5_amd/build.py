@@ -18,6 +18,9 @@ OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(CSRC, "libf5hip.so")
 UNITS = ["f5hip.hip", "tu_gemm_reg.hip", "tu_gemm3.hip", "tu_gemm5_generic.hip", "tu_gemm5_qkv.hip", "tu_conv5.hip", "tu_attn.hip"]
 HOT = ("gemm", "conv5", "attn", "ln_kernel")   # kernels that must not touch scratch memory
+# Per-unit flags.  tu_attn: hipcc's SLP vectorizer turns the softmax row sums into v_pk_add_f32, which beside MFMAs costs more issue time than
+# the two v_add_f32 it replaces (MI355X_MICROARCH "packed f32 VALU ... an anti-lever beside MFMAs"); measured in profiles/r02_attn_bench.txt.
+UNIT_FLAGS = {"tu_attn.hip": ["-fno-slp-vectorize"]}
 
 _INC = re.compile(r'^\s*#\s*include\s+"([^"]+)"', re.M)
 
@@ -42,7 +45,7 @@ def _compile(unit: str, flags: list[str], verbose: bool):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     # -Rpass-analysis=kernel-resource-usage: per-kernel VGPR / scratch report.  A hot kernel that touches scratch pays a
     # scratch set-up per wave plus the spills (a run-time index into the by-value argument struct once cost every GEMM 7 us).
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", "-Rpass-analysis=kernel-resource-usage", *flags, "-o", obj, src]
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", "-Rpass-analysis=kernel-resource-usage", *flags, *UNIT_FLAGS.get(unit, []), "-o", obj, src]
     if verbose:
         print("[build]", " ".join(cmd), flush=True)
     r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
@@ -96,7 +99,9 @@ def build(force: bool = False, verbose: bool = True, experiments: bool = False) 
             lines += open(o + ".resources").read().splitlines()
     with open(os.path.join(CSRC, "kernel_resources.txt"), "w") as f:
         f.write("\n".join(lines) + "\n")
-    hot = [l.split("VGPR", 1)[1].strip() for l in lines if not l.lstrip().startswith("0 B") and any(k in l for k in HOT)]
+    # (attn3's STAMPS = true instantiations exist only in --experiments builds, for tools/attn_stamps.py: not production kernels)
+    hot = [l.split("VGPR", 1)[1].strip() for l in lines if not l.lstrip().startswith("0 B") and any(k in l for k in HOT)
+           and not re.search(r"attn3_fwd_kernelILi\dELb\dELb1EE", l)]
     if hot:
         raise RuntimeError("hot kernels use scratch memory: " + ", ".join(hot))
     return LIB

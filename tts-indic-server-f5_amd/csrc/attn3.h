@@ -1,47 +1,83 @@
-// attn3: attn2 with the QK^T MFMAs of KV tile j+1 issued BEFORE the softmax of tile j (software pipelining inside each wave).
+// attn3: flash-style attention forward.  S^T = K Q^T, so a query is a lane and its row statistics are in-register; exp(S) is directly the
+// B operand of O^T += V^T P^T.  A wave owns QB blocks of 32 queries; a workgroup = NW waves = one query tile of 32 QB NW queries; K / V^T
+// tiles of 64 keys stream through an LDS ring by LDS-DMA.
 //
-// rocprof + cycle counts on attn2 (MI355X, N = 1404): ~3800 cycles per KV tile and SIMD against ~1000 cycles of MFMA
-// (2 waves x 16 MFMAs) and ~2200 cycles of VALU (2 waves x 32 exp2 at quarter rate + max / sum / scale / convert):
-// the per-tile barrier keeps the two waves of a SIMD in lockstep, so matrix and vector phases add up instead of
-// overlapping.  Here each wave carries two score accumulators: S_next = K_{j+1} Q^T goes to the matrix pipe, then the
-// softmax of S_cur runs on the VALU while those MFMAs execute, then O += V_j P.  The LDS ring is 5 deep so the K tile
-// one step ahead is resident while 3 more tiles stay in flight.
+// History of the inner loop (MI355X, C2 shape N = 1404 x 16 heads x 2, tools/attn_stamps.py / attn_bench.py, profiles/r02_attn_bench.txt):
+//   attn2   ~3800 cycles per KV tile and SIMD against ~1000 of MFMA and ~2200 of VALU: the per-tile barrier keeps the two waves of a SIMD
+//           in lockstep, so matrix and vector phases add up instead of overlapping;
+//   attn3a  each wave carries two score tiles, S_next = K_{j+1} Q^T issued before the softmax of S_cur: 2940 per tile, 45.7 us -- the
+//           stamps showed the overlap never happened: a wave is in-order, the 8 score MFMAs went out back to back (the wave sits in MFMA
+//           issue for 256+ cycles with its VALU idle), then the max chain ran with the matrix pipe idle, then exp2 + PV;
+//   now     (1) fixed-offset softmax (below): a third fewer VALU issue cycles, no data-dependent branch in the loop;
+//           (2) half-tile steps (32 keys = one 32 x 32 score block per query block), each ONE straight-line scheduling region in which
+//               sched_group_barrier spreads the MFMAs one : two exp2 : four plain VALU;
+//           (3) V^T stored in vt_col order (common.h): a PV fragment is one ds_read_b128, no register shuffle; fragment addresses from
+//               one lane constant by XOR;
+//           (4) fragments prefetched one half tile ahead (no MFMA waits on LDS latency);
+//           (5) XCD-aware workgroup numbering: the query tiles of one (sequence, head) share an L2;
+//           (6) QB = 2: 64 queries per wave, one wave per SIMD with the 512-register budget -- every K / V^T fragment read from LDS feeds two
+//               MFMAs, there is no partner wave to share the SIMD's issue slots with, and NW = 4 puts exactly one wave on each SIMD
+//               (with 6 waves of 32 queries two SIMDs carried two waves, two carried one, and every tile ended at a barrier).
 #pragma once
+#include <type_traits>
 #include "attn_common.h"
 
-// NW = waves per workgroup = 32-query slices per query tile (4, 6 or 8).  The launcher picks NW so that the grid fills the 256 CUs in
-// whole rounds: at the C2 shape (2 sequences x 16 heads x 1404 queries) 256-query tiles give 192 workgroups -- 64 CUs idle for the whole
-// launch -- while 192-query tiles (NW = 6) give exactly 256 workgroups with 3/4 of the work each.
-// SEG2: the keys are two row ranges (AttnArgs::seq_kv_row0 / seq_kv2_*): tile kt covers 64 rows of the first range while kt < nkt1, of
-// the second after it; the last tile of EACH range is masked.  SEG2 = false is the single-range kernel of the DiT / UNetT path, unchanged.
-template <int NW, bool SEG2 = false>
-static __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn3_fwd_kernel(const AttnArgs p) {
-    constexpr int NST = 5, STAGE = 16384;
+// NW = waves per workgroup (4, 6 or 8), QB = 32-query blocks per wave (1 or 2), NST = ring stages of 16 KiB.
+// SEG2: the keys are two row ranges (AttnArgs::seq_kv_row0 / seq_kv2_*): tile kt covers 64 rows of the first range while kt < nkt1, of the
+// second after it; the last tile of EACH range is masked.  SEG2 = false is the single-range kernel of the DiT / UNetT path.
+//
+// Softmax with a FIXED per-query offset folded into the score MFMAs.  q arrives scaled by log2(e) / 8 (F5_Q_SCALE), so a score is already
+// a base-2 exponent.  Floating point is scale-invariant: the running maximum of online softmax only has to keep exp2 inside the fp32
+// range, it does not have to be the maximum.  So the offset of a query is its row maximum over the FIRST 32 keys and stays put: the first
+// MFMA of every later score block takes C = splat(-off) instead of 0, the accumulator leaves the matrix pipe as s - off, and exp2 applies
+// to it directly -- per score one exp2, one add, half a convert; no max, no subtract, no scale, no rescaling of O, no branch.  Whether every
+// probability stayed in range is decided ONCE, after the loop, from the largest row sum a lane saw (one v_max per half tile): if one did
+// not (needs a logit 48 nats above the query's maximum over its first 32 keys), the WHOLE workgroup redoes its tile with a plain
+// running-maximum loop -- correct for any input, and exercised by tests/test_gpu_ops.py (k_gain cases).
+// (The running-maximum formulation in the hot loop measured 45.7 us at C2 against 41.4 us for the fixed offset, before any of the
+// scheduling work.)
+template <int NW, bool SEG2 = false, bool STAMPS = false, int NST = 5, int QB = 1>
+static __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(QB == 2 ? 1 : 2, QB == 2 ? 1 : 2))) void attn3_fwd_kernel(const AttnArgs p) {
+    constexpr int STAGE = 16384;   // one 64-key tile: 8 KiB of K rows + 8 KiB of V^T rows
     constexpr int P_HI = (16 + NW - 1) / NW, P_LO = 16 / NW;   // 1 KiB pieces of a KV tile per wave (pieces w, w + NW, ...)
+    constexpr int QT = 32 * QB * NW;                            // queries per workgroup
     __shared__ __attribute__((aligned(16))) char smem[NST * STAGE];
-    const int seq = blockIdx.z, head = blockIdx.y;
+    // Workgroup -> (query tile, head, sequence), XCD-aware: the hardware deals consecutive workgroup ids round-robin to the 8 XCDs, which would
+    // put the query tiles of one (sequence, head) -- the workgroups that read the same K / V^T rows -- on 8 different L2s, each of them pulling
+    // every row from beyond L2.  Re-number so that an XCD gets a contiguous run of (sequence, head, tile) triples, tile fastest.
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    {
+        const unsigned gx = gridDim.x, gy = gridDim.y, total = gx * gy * gridDim.z, per = total >> 3;
+        const unsigned lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+        if (lin < per * 8) {
+            const unsigned v = (lin & 7) * per + (lin >> 3);
+            bx = (int)(v % gx); by = (int)((v / gx) % gy); bz = (int)(v / (gx * gy));
+        }
+    }
+    const int seq = bz, head = by;
     const int len = p.seq_len[seq], kvlen = p.seq_kvlen[seq], row0 = p.seq_row0[seq];
     const int kv_row0 = SEG2 ? p.seq_kv_row0[seq] : row0, kv2_row0 = SEG2 ? p.seq_kv2_row0[seq] : 0, kv2_len = SEG2 ? p.seq_kv2_len[seq] : 0;
     const int nkt1 = (kvlen + 63) >> 6;
-    const int q0 = blockIdx.x * (32 * NW);
+    const int q0 = bx * QT;
     if (q0 >= len) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 31, fh = lane >> 5;
     const int D = p.D;
-    const float LOG2E = 1.4426950408889634f;
 
-    // queries of this wave (rows beyond the sequence stay inside its 128-row padding or the next sequence: finite data,
-    // never stored).  q0 + 255 can exceed the padded rows of the LAST sequence only by < 256 rows: workspace has slack.
-    bf16x8 qf[4];
-    {
-        const __bf16* qrow = p.qk + (size_t)(row0 + q0 + wave * 32 + fr) * (2 * D) + head * 64 + fh * 8;
+    // queries of this wave (rows beyond the sequence stay inside its 128-row padding or the next sequence: finite data, never stored).
+    // q0 + QT - 1 can exceed the padded rows of the LAST sequence only by < 256 rows: the workspace has that much slack.
+    bf16x8 qf[QB][4];
 #pragma unroll
-        for (int s = 0; s < 4; s++) qf[s] = *reinterpret_cast<const bf16x8*>(qrow + s * 16);
+    for (int qb = 0; qb < QB; qb++) {
+        const __bf16* qrow = p.qk + (size_t)(row0 + q0 + (wave * QB + qb) * 32 + fr) * (2 * D) + head * 64 + fh * 8;
+#pragma unroll
+        for (int s = 0; s < 4; s++) qf[qb][s] = *reinterpret_cast<const bf16x8*>(qrow + s * 16);
     }
     // Retire the Q loads BEFORE the first LDS-DMA is issued: with a DMA in flight hipcc can only wait vmcnt(0) for an
     // ordinary VGPR load, and it would put that wait inside the KV loop, draining the ring every tile.
-    asm volatile("" ::"v"(qf[0]), "v"(qf[1]), "v"(qf[2]), "v"(qf[3]) : "memory");
+#pragma unroll
+    for (int qb = 0; qb < QB; qb++) asm volatile("" ::"v"(qf[qb][0]), "v"(qf[qb][1]), "v"(qf[qb][2]), "v"(qf[qb][3]) : "memory");
 
     // LDS-DMA: a KV tile is 8 K pieces + 8 V^T pieces of 1 KiB (8 rows x 128 B); wave w moves pieces w, w + NW, ... (0-7 = K, 8-15 = V^T).
     // Physical 16-B slot (lane & 7) of row r holds logical chunk (lane & 7) ^ ((r >> 1) & 7)  (same swizzle as the fragment reads).
@@ -69,117 +105,30 @@ static __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
     };
     // this wave's pieces of a tile have landed when at most `newer` younger tiles of its own are in flight
     auto wait_landed = [&](int newer) {
-        if (mine == P_HI) {
-            if (newer >= 3) attn_wait_vmcnt<3 * P_HI>(); else if (newer == 2) attn_wait_vmcnt<2 * P_HI>(); else if (newer == 1) attn_wait_vmcnt<P_HI>(); else attn_wait_vmcnt<0>();
-        } else {
-            if (newer >= 3) attn_wait_vmcnt<3 * P_LO>(); else if (newer == 2) attn_wait_vmcnt<2 * P_LO>(); else if (newer == 1) attn_wait_vmcnt<P_LO>(); else attn_wait_vmcnt<0>();
+        switch (newer * mine) {   // (wave-uniform; vmcnt takes an immediate)
+#define A3_W(N) case N: attn_wait_vmcnt<N>(); break;
+            A3_W(0) A3_W(1) A3_W(2) A3_W(3) A3_W(4) A3_W(5) A3_W(6) A3_W(7) A3_W(8) A3_W(9) A3_W(10) A3_W(11) A3_W(12) A3_W(13) A3_W(14) A3_W(15) A3_W(16)
+            A3_W(17) A3_W(18) A3_W(19) A3_W(20) A3_W(21) A3_W(22) A3_W(23) A3_W(24) A3_W(25) A3_W(26) A3_W(27) A3_W(28) A3_W(29) A3_W(30) A3_W(31) A3_W(32)
+#undef A3_W
+            default: attn_wait_vmcnt<0>(); break;
         }
     };
+    static_assert((NST - 2) * P_HI <= 32, "wait_landed covers 32 outstanding pieces");
 
-    f32x16 oacc[2];
+    f32x16 oacc[QB][2];
+    f32x16 negm[QB];                   // C operand of the first score MFMA of a block = splat(-offset); zero for the first block, fixed after it
+    float lrun[QB];
 #pragma unroll
-    for (int dt = 0; dt < 2; dt++)
+    for (int qb = 0; qb < QB; qb++) {
+        lrun[qb] = 0.0f;
 #pragma unroll
-        for (int g = 0; g < 16; g++) oacc[dt][g] = 0.0f;
-    float mrun = -1e30f, lrun = 0.0f;
+        for (int g = 0; g < 16; g++) { oacc[qb][0][g] = 0.0f; oacc[qb][1][g] = 0.0f; negm[qb][g] = 0.0f; }
+    }
 
-    const int nkt = nkt1 + (SEG2 ? (kv2_len + 63) >> 6 : 0);
-#pragma unroll
-    for (int t = 0; t < NST - 1; t++)
-        if (t < nkt) issue_tile(t);
-
-    // S^T tile = K_tile Q^T for the 64 keys of ring stage `st` (8 MFMAs), masked on the last, partial tile
-    auto qk_tile = [&](f32x16 (&s)[2], int kt) {
-        const char* kst = smem + (kt % NST) * STAGE;
-#pragma unroll
-        for (int kh = 0; kh < 2; kh++) {
-#pragma unroll
-            for (int g = 0; g < 16; g++) s[kh][g] = 0.0f;
-#pragma unroll
-            for (int sI = 0; sI < 4; sI++) {
-                bf16x8 kf = *reinterpret_cast<const bf16x8*>(kst + lds_off128(kh * 32 + fr, 2 * sI + fh));
-                s[kh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[sI], s[kh], 0, 0, 0);
-            }
-        }
-        // keys of this tile that exist: the rest of its range (a tile never straddles the two ranges)
-        const int valid = (!SEG2 || kt < nkt1) ? kvlen - kt * 64 : kv2_len - (kt - nkt1) * 64;
-        if (valid < 64) {   // key-padding mask
-#pragma unroll
-            for (int kh = 0; kh < 2; kh++)
-#pragma unroll
-                for (int g = 0; g < 16; g++) {
-                    const int key = kh * 32 + (g & 3) + 8 * (g >> 2) + 4 * fh;
-                    if (key >= valid) s[kh][g] = -1e30f;
-                }
-        }
-    };
-
-    typedef __attribute__((ext_vector_type(2))) float f32x2;
-    // softmax of one score tile + O += V P for ring stage of tile `kt` (packed fp32 VALU ops: two scores per instruction)
-    auto softmax_pv = [&](f32x16 (&sacc)[2], int kt) {
-        const char* vst = smem + (kt % NST) * STAGE + 8192;
-        float mloc = sacc[0][0];
-#pragma unroll
-        for (int kh = 0; kh < 2; kh++)
-#pragma unroll
-            for (int g = 0; g < 16; g++) mloc = fmaxf(mloc, sacc[kh][g]);
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-        const float mnew = fmaxf(mrun, mloc);
-        const bool moved = mnew != mrun;
-        const float alpha = __builtin_amdgcn_exp2f((mrun - mnew) * LOG2E);
-        mrun = mnew;
-        const f32x2 msc2 = {-mnew * LOG2E, -mnew * LOG2E}, l2e2 = {LOG2E, LOG2E};
-        f32x2 rs2 = {0.0f, 0.0f};
-#pragma unroll
-        for (int kh = 0; kh < 2; kh++)
-#pragma unroll
-            for (int g = 0; g < 16; g += 2) {
-                f32x2 t = {sacc[kh][g], sacc[kh][g + 1]};
-                t = __builtin_elementwise_fma(t, l2e2, msc2);
-                t[0] = __builtin_amdgcn_exp2f(t[0]);
-                t[1] = __builtin_amdgcn_exp2f(t[1]);
-                sacc[kh][g] = t[0];
-                sacc[kh][g + 1] = t[1];
-                rs2 += t;
-            }
-        lrun = lrun * alpha + (rs2[0] + rs2[1]);
-        if (__any(moved)) {   // wave-uniform; alpha == 1 exactly for every query whose maximum did not move
-#pragma unroll
-            for (int dt = 0; dt < 2; dt++)
-#pragma unroll
-                for (int g = 0; g < 16; g++) oacc[dt][g] *= alpha;
-        }
-#pragma unroll
-        for (int kh = 0; kh < 2; kh++) {
-#pragma unroll
-            for (int s2 = 0; s2 < 2; s2++) {
-                bf16x8 pf;
-#pragma unroll
-                for (int j = 0; j < 8; j++) pf[j] = (__bf16)sacc[kh][8 * s2 + j];
-#pragma unroll
-                for (int dt = 0; dt < 2; dt++) {
-                    const int row = dt * 32 + fr, c0 = kh * 4 + s2 * 2;
-                    const bf16x4 v0 = *reinterpret_cast<const bf16x4*>(vst + lds_off128(row, c0) + fh * 8);
-                    const bf16x4 v1 = *reinterpret_cast<const bf16x4*>(vst + lds_off128(row, c0 + 1) + fh * 8);
-                    bf16x8 vf;
-#pragma unroll
-                    for (int e = 0; e < 4; e++) { vf[e] = v0[e]; vf[4 + e] = v1[e]; }
-                    oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[dt], 0, 0, 0);
-                }
-            }
-        }
-    };
-    // ring step kt: tile kt + 1 landed (its K feeds the next score tile); every wave is past step kt - 1, so stage (kt - 1) % NST is free
-    auto ring_step = [&](int kt) {
-        wait_landed(min(2, nkt - 2 - kt));   // tiles kt + 2, kt + 3 may stay in flight
-        __builtin_amdgcn_s_barrier();
-        if (kt + NST - 1 < nkt) issue_tile(kt + NST - 1);
-    };
-
-    unsigned long long st_acc[4] = {0, 0, 0, 0}, st_prev = 0;
-    const bool st_on = p.dbg != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && wave == 0;
+    unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_prev = 0;
+    const bool st_on = STAMPS && p.dbg != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && wave == 0;
 #define A3_STAMP(I)                                                                                  \
-    if (st_on) {                                                                                     \
+    if (STAMPS && st_on) {                                                                           \
         unsigned long long t_;                                                                       \
         __builtin_amdgcn_sched_barrier(0);                                                           \
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                  \
@@ -187,51 +136,265 @@ static __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
         if ((I) >= 0) st_acc[(I) < 0 ? 0 : (I)] += t_ - st_prev;                                     \
         st_prev = t_;                                                                                \
     }
-    f32x16 sa[2], sb[2];   // the two score tiles swap roles every step (loop unrolled by two: no register copies)
-    // tile 0 must have landed before the first score tile: tiles 1..3 may stay in flight
-    wait_landed(min(3, nkt - 1));
+    const int nkt = nkt1 + (SEG2 ? (kv2_len + 63) >> 6 : 0);
+#pragma unroll
+    for (int t = 0; t < NST - 1; t++)
+        if (t < nkt) issue_tile(t);
+
+    // The unit of the inner loop is a HALF tile: 32 keys = one 32 x 32 score block per query block (16 registers; two whole 64-key score
+    // tiles in flight cost 64 and pushed the kernel into spills and accumulator copies).
+    // Fragment addresses: lds_off128(h * 32 + fr, 2 sI + fh) = fr * 128 + h * 4096 + (((2 sI) ^ (fh ^ sw)) << 4) with sw = (fr >> 1) & 7 -- ONE lane
+    // constant, the k-step is an XOR on address bits 5-6, the key half an immediate offset.  The V^T fragments (feature rows, 16-key k-steps in
+    // vt_col order) have the same form.
+    const unsigned k_lane = (unsigned)(fr * 128 + ((fh ^ ((fr >> 1) & 7)) << 4));
+    const unsigned v_lane = k_lane + 8192u;
+    auto stage_of = [&](int kt) { return (unsigned)((kt % NST) * STAGE); };
+    auto qk_read = [&](bf16x8 (&kf)[4], int kt, int h) {
+        const unsigned kb = stage_of(kt) + k_lane;
+#pragma unroll
+        for (int sI = 0; sI < 4; sI++) kf[sI] = *reinterpret_cast<const bf16x8*>(smem + (kb ^ (unsigned)(sI << 5)) + h * 4096);
+    };
+    // S^T block = K_half Q^T - offset (four chained MFMAs; C of the first = negm)
+    auto qk_mfma = [&](f32x16& s, const bf16x8 (&kf)[4], int qb) {
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[qb][0], negm[qb], 0, 0, 0);
+#pragma unroll
+        for (int sI = 1; sI < 4; sI++) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[sI], qf[qb][sI], s, 0, 0, 0);
+    };
+    // V^T fragments of k-step s2 of key half h (16 keys, stored in vt_col order: a lane's 8 keys are contiguous): one 16-byte read per 32 features
+    auto v_read = [&](bf16x8 (&vf)[2], unsigned vb, int h, int s2) {
+#pragma unroll
+        for (int dt = 0; dt < 2; dt++) vf[dt] = *reinterpret_cast<const bf16x8*>(smem + (vb ^ (unsigned)((h * 2 + s2) << 5)) + dt * 4096);
+    };
+    // key-padding mask of half h of tile kt (only the last tile of a key range is partial)
+    auto mask_half = [&](f32x16& s, int kt, int h) {
+        const int valid = ((!SEG2 || kt < nkt1) ? kvlen - kt * 64 : kv2_len - (kt - nkt1) * 64) - h * 32;   // (a tile never straddles the two ranges)
+        if (valid < 32) {
+#pragma unroll
+            for (int g = 0; g < 16; g++) {
+                const int key = (g & 3) + 8 * (g >> 2) + 4 * fh;
+                if (key >= valid) s[g] = -1e30f;
+            }
+        }
+    };
+    auto row_max = [&](const f32x16& s) {
+        float m = s[0];
+#pragma unroll
+        for (int g = 1; g < 16; g++) m = fmaxf(m, s[g]);
+        return fmaxf(m, __shfl_xor(m, 32, 64));
+    };
+    // ring step kt: tile kt + 1 landed (its K feeds the next score block); every wave is past tile kt - 1, so stage (kt - 1) % NST is free
+    auto ring_step = [&](int kt) {
+        wait_landed(min(NST - 3, nkt - 2 - kt));   // tiles kt + 2 .. kt + NST - 2 may stay in flight
+        A3_STAMP(5);
+        __builtin_amdgcn_s_barrier();
+        A3_STAMP(4);
+        if (kt + NST - 1 < nkt) issue_tile(kt + NST - 1);
+    };
+    // ---- one half tile of the FAST loop: straight-line, no branch on the data ------------------------------------------------------------
+    // ONE scheduling region: per query block the four score MFMAs of the NEXT half and the four O^T += V^T P^T MFMAs of THIS half, spread one
+    // MFMA : two exp2 : a few plain VALU (an in-order wave that issues MFMAs back to back sits in MFMA issue with its VALU idle, and one
+    // that runs its VALU in one block leaves the matrix pipe idle); exp2 / row sum / convert of this half (scores are s - off: exp2 directly).
+    // The fragments a half tile multiplies were read from LDS during the PREVIOUS half tile (two register sets that swap roles), so no MFMA
+    // waits on LDS latency; ring step kt (tile kt + 1 landed and visible) therefore comes at the top of tile kt, before its first half
+    // prefetches K rows of tile kt + 1.
+    // H: which half of tile kt `sc` holds.  The block produced here is (kt, 1) for H = 0 and (kt + 1, 0) for H = 1.
+    // NEXT_TILE: tile kt + 1 exists.  MASK: the score block produced here belongs to a possibly partial tile.
+    float rs_max = 0.0f;
+    struct Frags { bf16x8 k[4]; bf16x8 v[2][2]; };
+    auto fast_half = [&](f32x16 (&sc)[QB], int kt, Frags& use, Frags& fill, auto h_t, auto next_tile_t, auto mask_t) {
+        constexpr int H = decltype(h_t)::value;
+        constexpr bool NEXT_TILE = decltype(next_tile_t)::value, MASK = decltype(mask_t)::value;
+        constexpr bool HAS_NEXT = H == 0 || NEXT_TILE;
+        if (H == 0) {
+            ring_step(kt);
+            A3_STAMP(0);
+        }
+        // prefetch for the following half tile: H = 0 -> (kt, 1) multiplies K(kt + 1, rows 0-31) and V(kt, keys 32-63);
+        //                                      H = 1 -> (kt + 1, 0) multiplies K(kt + 1, rows 32-63) and V(kt + 1, keys 0-31)
+        if (NEXT_TILE) qk_read(fill.k, kt + 1, H == 0 ? 0 : 1);
+        if (H == 0) {
+            const unsigned vb = stage_of(kt) + v_lane;
+            v_read(fill.v[0], vb, 1, 0);
+            v_read(fill.v[1], vb, 1, 1);
+        } else if (NEXT_TILE) {
+            const unsigned vb = stage_of(kt + 1) + v_lane;
+            v_read(fill.v[0], vb, 0, 0);
+            v_read(fill.v[1], vb, 0, 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int qb = 0; qb < QB; qb++) {
+            f32x16 acc;
+            if (HAS_NEXT) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(use.k[0], qf[qb][0], negm[qb], 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(use.k[1], qf[qb][1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(use.k[2], qf[qb][2], acc, 0, 0, 0);
+            }
+            float pe[16], r4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            bf16x8 pf[2];
+#pragma unroll
+            for (int g = 0; g < 16; g++) {
+                pe[g] = __builtin_amdgcn_exp2f(sc[qb][g]);
+                r4[g & 3] += pe[g];
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; s2++) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) pf[s2][j] = (__bf16)pe[8 * s2 + j];
+#pragma unroll
+                for (int dt = 0; dt < 2; dt++) oacc[qb][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(use.v[s2][dt], pf[s2], oacc[qb][dt], 0, 0, 0);
+            }
+            const float rs = (r4[0] + r4[1]) + (r4[2] + r4[3]);
+            lrun[qb] += rs;
+            rs_max = fmaxf(rs_max, rs);   // (v_max drops a NaN operand: an inf - inf cannot occur here, and rows of padding queries are never stored)
+            if (HAS_NEXT) sc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(use.k[3], qf[qb][3], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < QB * (HAS_NEXT ? 8 : 4); i++) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+        }
+        if (HAS_NEXT && (SEG2 || MASK)) {
+#pragma unroll
+            for (int qb = 0; qb < QB; qb++) mask_half(sc[qb], H == 0 ? kt : kt + 1, H == 0 ? 1 : 0);
+        }
+        A3_STAMP(H == 0 ? 1 : 2);
+    };
+
+    f32x16 sa[QB];   // the score blocks of the half tile about to be consumed
+    Frags fa, fb;
+    // tile 0 must have landed before the first score block: tiles 1 .. NST - 2 may stay in flight
+    wait_landed(min(NST - 2, nkt - 1));
     __builtin_amdgcn_s_barrier();
-    qk_tile(sa, 0);
-    A3_STAMP(-1);
-    for (int kt = 0; kt < nkt; kt += 2) {
-        ring_step(kt);
-        A3_STAMP(0);
-        if (kt + 1 < nkt) qk_tile(sb, kt + 1);
-        A3_STAMP(1);
-        softmax_pv(sa, kt);
-        A3_STAMP(2);
-        if (kt + 1 >= nkt) break;
-        ring_step(kt + 1);
-        A3_STAMP(0);
-        if (kt + 2 < nkt) qk_tile(sa, kt + 2);
-        A3_STAMP(1);
-        softmax_pv(sb, kt + 1);
-        A3_STAMP(2);
+    {
+        bf16x8 kf0[4];
+        qk_read(kf0, 0, 0);
+#pragma unroll
+        for (int qb = 0; qb < QB; qb++) qk_mfma(sa[qb], kf0, qb);   // (C = 0: negm is still zero)
     }
-    if (st_on && lane == 0) { p.dbg[0] = st_acc[0]; p.dbg[1] = st_acc[1]; p.dbg[2] = st_acc[2]; p.dbg[3] = (unsigned long long)nkt; }
+    qk_read(fa.k, 0, 1);    // what half (0, 0) multiplies: K rows 32-63 and V keys 0-31 of tile 0
+    v_read(fa.v[0], stage_of(0) + v_lane, 0, 0);
+    v_read(fa.v[1], stage_of(0) + v_lane, 0, 1);
+#pragma unroll
+    for (int qb = 0; qb < QB; qb++) {   // the queries' offsets = their maxima over the first 32 keys (masked ones are -1e30; key 0 is always valid)
+        mask_half(sa[qb], 0, 0);
+        const float m0 = row_max(sa[qb]);
+#pragma unroll
+        for (int g = 0; g < 16; g++) { negm[qb][g] = -m0; sa[qb][g] -= m0; }
+    }
+    A3_STAMP(-1);
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    using H0 = std::integral_constant<int, 0>;
+    using H1 = std::integral_constant<int, 1>;
+    int kt = 0;
+    for (; kt + 2 < nkt; kt++) {   // tiles whose successors are complete tiles: no masks
+        fast_half(sa, kt, fa, fb, H0{}, T_{}, F_{});
+        fast_half(sa, kt, fb, fa, H1{}, T_{}, F_{});
+    }
+    for (; kt < nkt; kt++) {   // the last one or two tiles
+        if (kt + 1 < nkt) {
+            fast_half(sa, kt, fa, fb, H0{}, T_{}, T_{});
+            fast_half(sa, kt, fb, fa, H1{}, T_{}, T_{});
+        } else {
+            fast_half(sa, kt, fa, fb, H0{}, F_{}, T_{});
+            fast_half(sa, kt, fb, fa, H1{}, F_{}, F_{});
+        }
+    }
+    // Did every probability stay in range?  A lane's row sum over its 16 keys of a half bounds each of them; 2^70 leaves 2^57 of fp32 headroom
+    // for the sums over 4096 keys.  (The flag lives in the first bytes of the ring -- 5 x 16 KiB is exactly half a CU's LDS, two workgroups
+    // per CU -- hence the barriers: everybody done with the ring | flag cleared | flag set | flag read.)
+    int* redo_flag = reinterpret_cast<int*>(smem);
+    attn_wait_vmcnt<0>();
+    __syncthreads();
+    if (threadIdx.x == 0) *redo_flag = 0;
+    __syncthreads();
+    if (__any(!(rs_max <= 0x1p70f)) && lane == 0) *redo_flag = 1;
+    __syncthreads();
+    const bool redo = *redo_flag != 0;
+    __syncthreads();
+    if (redo) {   // GENERAL loop: running maximum, any input; plain code, one query block at a time
+        float mrun[QB];
+#pragma unroll
+        for (int qb = 0; qb < QB; qb++) {
+            lrun[qb] = 0.0f;
+            mrun[qb] = -1e30f;
+#pragma unroll
+            for (int g = 0; g < 16; g++) { oacc[qb][0][g] = 0.0f; oacc[qb][1][g] = 0.0f; negm[qb][g] = 0.0f; }
+        }
+#pragma unroll
+        for (int t = 0; t < NST - 1; t++)
+            if (t < nkt) issue_tile(t);
+        for (int gk = 0; gk < nkt; gk++) {
+            // tile gk landed for everybody; every wave is past tile gk - 1, so its stage can take tile gk + NST - 2
+            wait_landed(min(gk == 0 ? NST - 2 : NST - 3, nkt - 1 - gk));   // issued so far: tiles 0 .. NST - 2 at gk = 0, up to gk + NST - 3 after
+            __builtin_amdgcn_s_barrier();
+            if (gk > 0 && gk + NST - 2 < nkt) issue_tile(gk + NST - 2);
+            const unsigned vb = stage_of(gk) + v_lane;
+#pragma unroll 1
+            for (int h = 0; h < 2; h++) {
+                bf16x8 kf[4];
+                qk_read(kf, gk, h);
+#pragma unroll
+                for (int qb = 0; qb < QB; qb++) {
+                    f32x16 sg;
+                    qk_mfma(sg, kf, qb);
+                    mask_half(sg, gk, h);
+                    const float mnew = fmaxf(mrun[qb], row_max(sg));
+                    const float alpha = __builtin_amdgcn_exp2f(mrun[qb] - mnew);
+                    mrun[qb] = mnew;
+                    float rs = 0.0f;
+#pragma unroll
+                    for (int g = 0; g < 16; g++) {
+                        sg[g] = __builtin_amdgcn_exp2f(sg[g] - mnew);
+                        rs += sg[g];
+                    }
+                    lrun[qb] = lrun[qb] * alpha + rs;
+#pragma unroll
+                    for (int dt = 0; dt < 2; dt++)
+#pragma unroll
+                        for (int g = 0; g < 16; g++) oacc[qb][dt][g] *= alpha;
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; s2++) {
+                        bf16x8 pf, vf[2];
+#pragma unroll
+                        for (int j = 0; j < 8; j++) pf[j] = (__bf16)sg[8 * s2 + j];
+                        v_read(vf, vb, h, s2);
+#pragma unroll
+                        for (int dt = 0; dt < 2; dt++) oacc[qb][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[dt], pf, oacc[qb][dt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    if (STAMPS && st_on && lane == 0) { p.dbg[0] = st_acc[0]; p.dbg[1] = st_acc[1]; p.dbg[2] = st_acc[2]; p.dbg[3] = (unsigned long long)nkt; p.dbg[4] = st_acc[4]; p.dbg[5] = st_acc[5]; }
 #undef A3_STAMP
 
-    const float ltot = lrun + __shfl_xor(lrun, 32, 64);
-    const float inv = 1.0f / ltot;
-    const int q = q0 + wave * 32 + fr;
-    if (q < len) {
-        const size_t obase = (size_t)(row0 + q) * D + head * 64;
 #pragma unroll
-        for (int dt = 0; dt < 2; dt++)
+    for (int qb = 0; qb < QB; qb++) {
+        const float ltot = lrun[qb] + __shfl_xor(lrun[qb], 32, 64);
+        const float inv = 1.0f / ltot;
+        const int q = q0 + (wave * QB + qb) * 32 + fr;
+        if (q < len) {
+            const size_t obase = (size_t)(row0 + q) * D + head * 64;
 #pragma unroll
-            for (int a = 0; a < 4; a++) {
-                bf16x4 hi4, lo4;
-                float ov[4];
+            for (int dt = 0; dt < 2; dt++)
 #pragma unroll
-                for (int e = 0; e < 4; e++) ov[e] = oacc[dt][a * 4 + e] * inv;
-                const int d = dt * 32 + 8 * a + 4 * fh;
-                if (p.f16_out) {
-                    store_f16x4(p.out_hi + obase + d, ov);
-                    continue;
+                for (int a = 0; a < 4; a++) {
+                    bf16x4 hi4, lo4;
+                    float ov[4];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) ov[e] = oacc[qb][dt][a * 4 + e] * inv;
+                    const int d = dt * 32 + 8 * a + 4 * fh;
+                    if (p.f16_out) {
+                        store_f16x4(p.out_hi + obase + d, ov);
+                        continue;
+                    }
+                    split_bf16x4(ov, hi4, lo4);
+                    *reinterpret_cast<bf16x4*>(p.out_hi + obase + d) = hi4;
+                    if (p.out_lo) *reinterpret_cast<bf16x4*>(p.out_lo + obase + d) = lo4;
                 }
-                split_bf16x4(ov, hi4, lo4);
-                *reinterpret_cast<bf16x4*>(p.out_hi + obase + d) = hi4;
-                if (p.out_lo) *reinterpret_cast<bf16x4*>(p.out_lo + obase + d) = lo4;
-            }
+        }
     }
 }

@@ -11,7 +11,7 @@ struct AttnArgs {
     const int* seq_kvlen;
     // two-segment keys (attn3 SEG2 kernels; MMDiT joint attention, F/model/modules.py:496-514): the keys of (pseudo-)sequence s are rows
     // seq_kv_row0[s] .. + seq_kvlen[s] followed by rows seq_kv2_row0[s] .. + seq_kv2_len[s]; its queries are rows seq_row0[s] .. + seq_len[s],
-    // which may be either segment.  Segment starts are multiples of 8 rows (the V^T pieces are 16-byte aligned).
+    // which may be either segment.  Segment starts are multiples of 16 rows (V^T keeps tokens in vt_col order within aligned groups of 16).
     const int* seq_kv_row0;
     const int* seq_kv2_row0;
     const int* seq_kv2_len;

@@ -14,6 +14,13 @@ typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 
 #define F5_DEVICE __device__ __forceinline__
 
+// q leaves the QKV epilogue scaled by the softmax scale 1/8 AND log2(e), so an attention score is a base-2 exponent (attn3.h)
+#define F5_Q_SCALE (0.125f * 1.4426950408889634f)
+// V^T [feature][token] keeps the tokens of every aligned group of 16 in the order 0-3, 8-11, 4-7, 12-15 (bits 2 and 3 of the token index
+// swapped): the 8 tokens one lane feeds to a 32 x 32 x 16 PV MFMA -- rows {4 fh .. 4 fh + 3} and {8 + 4 fh ..} of the score block it holds --
+// are then 16 contiguous bytes, one ds_read_b128 instead of two 8-byte reads and a register shuffle (attn3.h).  Writers store 4-token groups.
+F5_DEVICE int vt_col(int tok) { return (tok & ~12) | ((tok & 4) << 1) | ((tok & 8) >> 1); }
+
 // fp32 -> (hi, lo) bf16 pair with hi = rn(x), lo = rn(x - hi): x ~= hi + lo to ~16 mantissa bits.
 F5_DEVICE void split_bf16(float x, __bf16& hi, __bf16& lo) {
     hi = (__bf16)x;

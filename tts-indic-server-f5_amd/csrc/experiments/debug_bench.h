@@ -112,12 +112,13 @@ extern "C" int f5hip_debug_attn_stamps(int32_t n, int32_t heads, int32_t iters, 
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int it = -2; it < iters; it++) {
         if (it == 0) hipEventRecord(e0, 0);
-        hipLaunchKernelGGL(attn3_fwd_kernel<8>, dim3((n + 255) / 256, heads, n_seq), dim3(512), 0, 0, at);
+        if (n <= 768) hipLaunchKernelGGL((attn3_fwd_kernel<4, false, true, 9, 2>), dim3((n + 255) / 256, heads, n_seq), dim3(256), 0, 0, at);   // 64 queries per wave   // one wave per SIMD, one workgroup per CU at heads = 12
+        else hipLaunchKernelGGL((attn3_fwd_kernel<6, false, true, 9>), dim3((n + 191) / 192, heads, n_seq), dim3(384), 0, 0, at);
     }
     hipEventRecord(e1, 0); hipEventSynchronize(e1);
     float ms = 0; hipEventElapsedTime(&ms, e0, e1);
     if (avg_us) *avg_us = (double)ms * 1e3 / iters;
-    hipMemcpy(out, dbg, 32, hipMemcpyDeviceToHost);
+    hipMemcpy(out, dbg, 48, hipMemcpyDeviceToHost);
     hipError_t e = hipGetLastError();
     for (void* p : {(void*)f, (void*)qk, (void*)vt, (void*)oh, (void*)ol, (void*)meta, (void*)dbg, (void*)lo_tmp}) hipFree(p);
     if (e != hipSuccess) return fail(-7, "attn stamps: %s", hipGetErrorString(e));

@@ -314,7 +314,7 @@ F5_DEVICE void g5_qk_rows(const GemmArgs& p, const float* slab, int m0, int n0, 
             if (n_base < 2 * D) {                                  // (wave-uniform)
                 const int which = n_base / D, nd = n_base - which * D + c4;
                 const f32x4 v = *reinterpret_cast<const f32x4*>(slab + rl * C::SLD + pn * 64 + c4) + bv[pn];
-                const float qs = which == 0 ? 0.125f : 1.0f;
+                const float qs = which == 0 ? F5_Q_SCALE : 1.0f;
                 bf16x4 o;
                 if (rot && pn == rot_pn) {
                     // explicit product + fma: left to the compiler, the contraction of a*c - b*s differed between instantiations of the
@@ -356,7 +356,7 @@ F5_DEVICE void g5_v_rows(const GemmArgs& p, const float* slab, int m0, int n0, i
         bf16x4 pk;
 #pragma unroll
         for (int e = 0; e < 4; e++) pk[e] = (__bf16)v[e];
-        if (tok < p.M) *reinterpret_cast<bf16x4*>(p.vt + (size_t)(n0 + f - 2 * p.D) * p.ldvt + tok) = pk;
+        if (tok < p.M) *reinterpret_cast<bf16x4*>(p.vt + (size_t)(n0 + f - 2 * p.D) * p.ldvt + vt_col(tok)) = pk;
     }
 }
 

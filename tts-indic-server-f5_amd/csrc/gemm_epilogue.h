@@ -191,7 +191,7 @@ F5_DEVICE void epi_qk_rows_t(const GemmArgs& p, const float* stg, int m_base, in
             sn[q] = *reinterpret_cast<const float2*>(p.rope_sin + pos * 32 + (nd >> 1));
         }
     }
-    const float qs = which == 0 ? 0.125f : 1.0f;
+    const float qs = which == 0 ? F5_Q_SCALE : 1.0f;
     __bf16* op = p.qk + (size_t)(m_base + r0) * (2 * D) + which * D + nd;
 #pragma unroll
     for (int q = 0; q < NQ; q++) {
@@ -262,7 +262,7 @@ F5_DEVICE void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[TM][TN], float* sl
                     bf16x4 pk;
 #pragma unroll
                     for (int e = 0; e < 4; e++) pk[e] = (__bf16)(acc[i][j][a4 * 4 + e] + bv);
-                    *reinterpret_cast<bf16x4*>(p.vt + (size_t)nd * p.ldvt + m_wave + i * 32 + 8 * a4 + 4 * fh) = pk;
+                    *reinterpret_cast<bf16x4*>(p.vt + (size_t)nd * p.ldvt + vt_col(m_wave + i * 32 + 8 * a4 + 4 * fh)) = pk;
                 }
             }
         return;
@@ -328,7 +328,7 @@ F5_DEVICE void gemm_epilogue8_consumer(const GemmArgs& p, f32x16 (&acc)[2][TN], 
                     bf16x4 pk;
 #pragma unroll
                     for (int e = 0; e < 4; e++) pk[e] = (__bf16)(acc[i][j][a4 * 4 + e] + bv);
-                    *reinterpret_cast<bf16x4*>(p.vt + (size_t)nd * p.ldvt + m_wave + i * 32 + 8 * a4 + 4 * fh) = pk;
+                    *reinterpret_cast<bf16x4*>(p.vt + (size_t)nd * p.ldvt + vt_col(m_wave + i * 32 + 8 * a4 + 4 * fh)) = pk;
                 }
             }
         return;                                        // (no barrier B for V blocks: the producers skip it too)

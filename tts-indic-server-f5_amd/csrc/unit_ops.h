@@ -205,12 +205,12 @@ __global__ __launch_bounds__(256) void op_pack_qkv_kernel(const float* q, const 
                                                           __bf16* qk, __bf16* vt) {
     const int row = blockIdx.x, src = row_src[row];
     for (int c = threadIdx.x; c < D; c += 256) {
-        const float qv = src >= 0 ? q[(size_t)src * D + c] * 0.125f : 0.0f;   // q is pre-scaled by 1/8 (QKV epilogue; exact in bf16)
+        const float qv = src >= 0 ? q[(size_t)src * D + c] * F5_Q_SCALE : 0.0f;   // q is pre-scaled by log2(e) / 8 like the QKV epilogue's
         const float kv = src >= 0 ? k[(size_t)src * D + c] : 0.0f;
         const float vv = src >= 0 ? v[(size_t)src * D + c] : 0.0f;
         qk[(size_t)row * 2 * D + c] = (__bf16)qv;
         qk[(size_t)row * 2 * D + D + c] = (__bf16)kv;
-        vt[(size_t)c * M_pad + row] = (__bf16)vv;
+        vt[(size_t)c * M_pad + vt_col(row)] = (__bf16)vv;
     }
 }
 __global__ __launch_bounds__(256) void op_unpack_planes_kernel(const __bf16* hi, const __bf16* lo, int D, const int* frame_row, float* out) {

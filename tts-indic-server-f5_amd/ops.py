@@ -40,7 +40,7 @@ def gemm(a, w, bias=None, *, prec=3, act="none", mul=None, res=None, row_keep=No
 
 
 def qkv(a, w, bias, row_pos, *, prec=3, iters=0):
-    """Fused QKV projection + epilogue.  Returns (q [M, D] (already / 8), k [M, D], v [M, D]) as fp32 views of the bf16 outputs, avg_us."""
+    """Fused QKV projection + epilogue.  Returns (q [M, D] (already scaled by log2(e) / 8), k [M, D], v [M, D]) as fp32 views of the bf16 outputs, avg_us."""
     dev = a.device
     M, D = a.shape
     M_pad = (M + 127) // 128 * 128
@@ -51,7 +51,10 @@ def qkv(a, w, bias, row_pos, *, prec=3, iters=0):
     us = C.c_double(0.0)
     _lib.check(_lib.lib().f5hip_op_qkv(M, D, _p(a), _p(w), _p(bias), _p(pos), prec, _p(qk), _p(vt), iters, C.byref(us),
                                        _lib.current_stream_ptr()), "f5hip_op_qkv")
-    return qk[:M, :D].float(), qk[:M, D:].float(), vt[:, :M].t().float(), us.value
+    # V^T keeps the tokens of every aligned group of 16 in the order 0-3, 8-11, 4-7, 12-15 (csrc/common.h vt_col): undo it for the caller
+    t = torch.arange(M_pad, device=dev)
+    col = (t & ~12) | ((t & 4) << 1) | ((t & 8) >> 1)
+    return qk[:M, :D].float(), qk[:M, D:].float(), vt[:, col[:M]].t().float(), us.value
 
 
 def layernorm(x, scale, shift, *, gain_off=1.0, eps=1e-6, rms=False):
