@@ -138,7 +138,7 @@ static __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
     }
     const int nkt = nkt1 + (SEG2 ? (kv2_len + 63) >> 6 : 0);
 #pragma unroll
-    for (int t = 0; t < NST - 1; t++)
+    for (int t = 0; t < (NST >= 9 ? NST : NST - 1); t++)
         if (t < nkt) issue_tile(t);
 
     // The unit of the inner loop is a HALF tile: 32 keys = one 32 x 32 score block per query block (16 registers; two whole 64-key score
@@ -182,8 +182,23 @@ static __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
         for (int g = 1; g < 16; g++) m = fmaxf(m, s[g]);
         return fmaxf(m, __shfl_xor(m, 32, 64));
     };
-    // ring step kt: tile kt + 1 landed (its K feeds the next score block); every wave is past tile kt - 1, so stage (kt - 1) % NST is free
+    // ring step kt: tile kt + 1 landed (its K feeds the next score block); every wave is past tile kt - 1, so stage (kt - 1) % NST is free.
+    // PAIR (the 9-stage ring of a lone workgroup): one step per TWO tiles -- at even kt tiles kt + 1 and kt + 2 are made visible and the
+    // stages of tiles kt - 2 and kt - 1 refilled; half the barriers (38 % of the wave cycles at C2 were parked at s_waitcnt / s_barrier:
+    // profiles/r02_pmc_attention_sq.txt).  The prologue fills the whole ring and makes tiles 0-2 visible.
+    constexpr bool PAIR = NST >= 9;
     auto ring_step = [&](int kt) {
+        if (PAIR) {
+            if ((kt & 1) || kt == 0) return;
+            // issued so far: tiles up to kt - 3 + NST (capped at nkt - 1); tiles kt + 1, kt + 2 must have landed
+            wait_landed(max(0, min(kt - 3 + NST, nkt - 1) - (kt + 2)));
+            A3_STAMP(5);
+            __builtin_amdgcn_s_barrier();
+            A3_STAMP(4);
+            if (kt - 2 + NST < nkt) issue_tile(kt - 2 + NST);
+            if (kt - 1 + NST < nkt) issue_tile(kt - 1 + NST);
+            return;
+        }
         wait_landed(min(NST - 3, nkt - 2 - kt));   // tiles kt + 2 .. kt + NST - 2 may stay in flight
         A3_STAMP(5);
         __builtin_amdgcn_s_barrier();
@@ -264,8 +279,9 @@ static __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
 
     f32x16 sa[QB];   // the score blocks of the half tile about to be consumed
     Frags fa, fb;
-    // tile 0 must have landed before the first score block: tiles 1 .. NST - 2 may stay in flight
-    wait_landed(min(NST - 2, nkt - 1));
+    // tile 0 must have landed before the first score block: tiles 1 .. NST - 2 may stay in flight (PAIR: tiles 0-2 landed, 3 .. NST - 1 in flight)
+    if (PAIR) wait_landed(max(0, min(NST - 1, nkt - 1) - 2));
+    else wait_landed(min(NST - 2, nkt - 1));
     __builtin_amdgcn_s_barrier();
     {
         bf16x8 kf0[4];
