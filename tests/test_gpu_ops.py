@@ -291,3 +291,17 @@ def test_joint_attention_vs_torch(x_len, c_len, x_kv):
         ox += n; oc += nt
     print(f"[parity] joint attention x {x_len} c {c_len} kv {x_kv}: max err {worst:.3e}")
     assert worst < 2e-2   # bf16 P and V operands (8 mantissa bits) over up to ~1.6 k keys; the single-range test uses the same bound
+
+
+def test_attention_random_shapes(monkeypatch):
+    """tools/attn_fuzz.py with a fixed seed: 24 random ragged batches (1-16 heads, key counts ending anywhere in a tile, a third of them with
+    logits far above the first key block) + 6 two-range cases, each against fp64 attention on the rounded operands, bound 2e-2 as above."""
+    import importlib.util
+    import os
+    import sys
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "attn_fuzz.py")
+    spec = importlib.util.spec_from_file_location("attn_fuzz", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    monkeypatch.setattr(sys, "argv", ["attn_fuzz.py", "24", "3"])
+    mod.main()   # exits non-zero on the first case out of bounds
