@@ -98,6 +98,12 @@ int f5hip_cfm_sample_masked(f5hip_dit* m, int32_t n_utt, const int32_t* dur, con
  * x += dt * v(t_i + dt / 2, x + dt / 2 * v(t_i, x)), two backbone evaluations per step, at most 64 steps per call. */
 int f5hip_dit_set_ode_method(f5hip_dit* m, int32_t method);
 
+/* Attention kernel choice.  0 (default): the fastest form per launch shape -- a launch with 192-query tiles (e.g. one 10 s utterance) runs
+ * the SIMD-balanced kernel, in which a third of the query blocks accumulate the two key halves of every tile separately and merge them at
+ * the end: the same sums in a different association, so a sequence's output can differ in the last bits (~the bf16 rounding noise of P)
+ * from what it gets inside a larger batch.  1: shape-invariant arithmetic -- every variant adds every query's terms in one order, so a
+ * sequence's output does not depend on what it is batched with (bit-identical); ~3 % slower at batch 1.  Process-wide. */
+int f5hip_set_attention_shape_invariant(int32_t on);
 /* Per-kernel timing of the last f5hip_cfm_sample call when profiling was enabled with
  * f5hip_set_profiling(1): average milliseconds per launch of the named kernel class
  * ("gemm", "attn", "ln", "other") measured with HIP events on the launch stream, and launch counts. */

@@ -17,3 +17,14 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture
+def attn_shape_invariant():
+    """f5hip_set_attention_shape_invariant(1) for the duration of a test: every attention variant then adds a query's terms in one order, so
+    a sequence's output does not depend on the shape of the launch it is part of (the default picks the fastest kernel per shape, and the
+    SIMD-balanced one associates the sums of a third of its query blocks differently)."""
+    from tts_indic_server_f5_amd import _lib
+    _lib.check(_lib.lib().f5hip_set_attention_shape_invariant(1), "set_attention_shape_invariant")
+    yield
+    _lib.check(_lib.lib().f5hip_set_attention_shape_invariant(0), "set_attention_shape_invariant")

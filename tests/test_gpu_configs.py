@@ -78,9 +78,10 @@ def base_model():
     return F5HipModel(F5TTS_BASE, synth.dit_state_dict())
 
 
-def test_c3_share_batch8_copies_equal_single(base_model):
+def test_c3_share_batch8_copies_equal_single(base_model, attn_shape_invariant):
     """8 identical utterances (M = 16 x 1408 rows: every block GEMM runs multi-round 176 x 128 / 176 x 192 tiles) give, item by item, the
-    batch-1 result (176 x 64 / 128 / 192 tiles in one round): only the tile shapes differ, the k order of every dot product does not."""
+    batch-1 result (176 x 64 / 128 / 192 tiles in one round): only the tile shapes differ, the k order of every dot product does not.
+    (Shape-invariant attention arithmetic: see conftest.attn_shape_invariant; the default mode is compared in test_gpu_dit.)"""
     gc = torch.Generator().manual_seed(14)
     cond = torch.randn(1, 469, 100, generator=gc)
     text = synth.text_ids()
@@ -95,7 +96,7 @@ def test_c3_share_batch8_copies_equal_single(base_model):
         assert _report(f"C3 share item {i}", eight[i], one[0]) < 2e-5
 
 
-def test_c3_ragged_batch8_is_per_item_batch1(base_model):
+def test_c3_ragged_batch8_is_per_item_batch1(base_model, attn_shape_invariant):
     """Ragged per-GPU share (generated lengths 6 .. 14 s): every item equals the item sampled alone."""
     gc = torch.Generator().manual_seed(15)
     cond = torch.randn(1, 469, 100, generator=gc)

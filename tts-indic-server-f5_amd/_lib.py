@@ -45,6 +45,7 @@ SYMBOLS = {
                                           C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),
     "f5hip_dit_set_ode_method": (C.c_int, [C.c_void_p, C.c_int32]),
     "f5hip_set_profiling": (C.c_int, [C.c_int32]),
+    "f5hip_set_attention_shape_invariant": (C.c_int, [C.c_int32]),
     "f5hip_get_profile": (C.c_int, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "f5hip_get_counter": (C.c_int, [C.c_char_p, C.POINTER(C.c_int64)]),
     "f5hip_op_gemm": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,

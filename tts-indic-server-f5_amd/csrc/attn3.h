@@ -36,11 +36,16 @@
 // running-maximum loop -- correct for any input, and exercised by tests/test_gpu_ops.py (k_gain cases).
 // (The running-maximum formulation in the hot loop measured 45.7 us at C2 against 41.4 us for the fixed offset, before any of the
 // scheduling work.)
-template <int NW, bool SEG2 = false, bool STAMPS = false, int NST = 5, int QB = 1>
+// BAL (NW = 8, QB = 1, 192 queries per workgroup): the SIMD-balanced form of the 6-block tile.  Eight waves put two on every SIMD; waves 0-3 own a
+// query block each over all keys, waves 4 / 5 own blocks 4 / 5 over keys 0-31 of every tile and waves 6 / 7 the SAME blocks over keys 32-63,
+// so every SIMD carries three half tiles per tile (with six whole-block waves two SIMDs carry four and two carry two, and the per-tile barrier
+// makes the four the pace).  The two halves of blocks 4 / 5 keep their own offset, O and l and are merged once at the end through LDS.
+template <int NW, bool SEG2 = false, bool STAMPS = false, int NST = 5, int QB = 1, bool BAL = false>
 static __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(QB == 2 ? 1 : 2, QB == 2 ? 1 : 2))) void attn3_fwd_kernel(const AttnArgs p) {
     constexpr int STAGE = 16384;   // one 64-key tile: 8 KiB of K rows + 8 KiB of V^T rows
     constexpr int P_HI = (16 + NW - 1) / NW, P_LO = 16 / NW;   // 1 KiB pieces of a KV tile per wave (pieces w, w + NW, ...)
-    constexpr int QT = 32 * QB * NW;                            // queries per workgroup
+    static_assert(!BAL || (NW == 8 && QB == 1), "BAL is the 8-wave, 6-block form");
+    constexpr int QT = BAL ? 192 : 32 * QB * NW;                // queries per workgroup
     __shared__ __attribute__((aligned(16))) char smem[NST * STAGE];
     // Workgroup -> (query tile, head, sequence), XCD-aware: the hardware deals consecutive workgroup ids round-robin to the 8 XCDs, which would
     // put the query tiles of one (sequence, head) -- the workgroups that read the same K / V^T rows -- on 8 different L2s, each of them pulling
@@ -64,13 +69,16 @@ static __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 31, fh = lane >> 5;
     const int D = p.D;
+    // BAL roles: 0 = whole tiles, 1 = keys 0-31 of every tile, 2 = keys 32-63; qblk = the 32-query block of the wave
+    const int role = !BAL ? 0 : wave < 4 ? 0 : wave < 6 ? 1 : 2;
+    const int qblk = !BAL ? wave * QB : wave < 6 ? wave : wave - 2;
 
     // queries of this wave (rows beyond the sequence stay inside its 128-row padding or the next sequence: finite data, never stored).
     // q0 + QT - 1 can exceed the padded rows of the LAST sequence only by < 256 rows: the workspace has that much slack.
     bf16x8 qf[QB][4];
 #pragma unroll
     for (int qb = 0; qb < QB; qb++) {
-        const __bf16* qrow = p.qk + (size_t)(row0 + q0 + (wave * QB + qb) * 32 + fr) * (2 * D) + head * 64 + fh * 8;
+        const __bf16* qrow = p.qk + (size_t)(row0 + q0 + (qblk + qb) * 32 + fr) * (2 * D) + head * 64 + fh * 8;
 #pragma unroll
         for (int s = 0; s < 4; s++) qf[qb][s] = *reinterpret_cast<const bf16x8*>(qrow + s * 16);
     }
@@ -277,25 +285,76 @@ static __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
         A3_STAMP(H == 0 ? 1 : 2);
     };
 
+    // BAL, roles 1 / 2: one half tile per tile -- consumes block (kt, H), produces block (kt + 1, H); fragments read at the top of the step
+    // (no prefetch across steps: K rows of tile kt + 2 are not visible yet; the whole-block wave on the same SIMD covers the latency)
+    auto half_only = [&](f32x16& sc, int kt, auto h_t, auto next_tile_t) {
+        constexpr int H = decltype(h_t)::value;
+        constexpr bool NEXT = decltype(next_tile_t)::value;
+        ring_step(kt);
+        bf16x8 kf[4], vf[2][2], pf[2];
+        if (NEXT) qk_read(kf, kt + 1, H);
+        const unsigned vb = stage_of(kt) + v_lane;
+        v_read(vf[0], vb, H, 0);
+        v_read(vf[1], vb, H, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        f32x16 acc;
+        if (NEXT) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[0][0], negm[0], 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1], qf[0][1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[2], qf[0][2], acc, 0, 0, 0);
+        }
+        float pe[16], r4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int g = 0; g < 16; g++) {
+            pe[g] = __builtin_amdgcn_exp2f(sc[g]);
+            r4[g & 3] += pe[g];
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; s2++) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) pf[s2][j] = (__bf16)pe[8 * s2 + j];
+#pragma unroll
+            for (int dt = 0; dt < 2; dt++) oacc[0][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[s2][dt], pf[s2], oacc[0][dt], 0, 0, 0);
+        }
+        const float rs = (r4[0] + r4[1]) + (r4[2] + r4[3]);
+        lrun[0] += rs;
+        rs_max = fmaxf(rs_max, rs);
+        if (NEXT) sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[3], qf[0][3], acc, 0, 0, 0);
+        // the first exp2 / adds / converts run while the fragments are on their way from LDS, then one MFMA : two exp2 : a few VALU
+        __builtin_amdgcn_sched_group_barrier(0x400, 6, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+#pragma unroll
+        for (int i = 0; i < (NEXT ? 8 : 4); i++) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+        }
+        if (NEXT) mask_half(sc, kt + 1, H);   // (tests the tile's key count itself)
+    };
+
     f32x16 sa[QB];   // the score blocks of the half tile about to be consumed
     Frags fa, fb;
+    const int h_first = (BAL && role == 2) ? 1 : 0;   // the half of tile 0 this wave starts with
     // tile 0 must have landed before the first score block: tiles 1 .. NST - 2 may stay in flight (PAIR: tiles 0-2 landed, 3 .. NST - 1 in flight)
     if (PAIR) wait_landed(max(0, min(NST - 1, nkt - 1) - 2));
     else wait_landed(min(NST - 2, nkt - 1));
     __builtin_amdgcn_s_barrier();
     {
         bf16x8 kf0[4];
-        qk_read(kf0, 0, 0);
+        if (BAL && role == 2) qk_read(kf0, 0, 1); else qk_read(kf0, 0, 0);
 #pragma unroll
         for (int qb = 0; qb < QB; qb++) qk_mfma(sa[qb], kf0, qb);   // (C = 0: negm is still zero)
     }
-    qk_read(fa.k, 0, 1);    // what half (0, 0) multiplies: K rows 32-63 and V keys 0-31 of tile 0
-    v_read(fa.v[0], stage_of(0) + v_lane, 0, 0);
-    v_read(fa.v[1], stage_of(0) + v_lane, 0, 1);
+    if (!BAL || role == 0) {
+        qk_read(fa.k, 0, 1);    // what half (0, 0) multiplies: K rows 32-63 and V keys 0-31 of tile 0
+        v_read(fa.v[0], stage_of(0) + v_lane, 0, 0);
+        v_read(fa.v[1], stage_of(0) + v_lane, 0, 1);
+    }
 #pragma unroll
-    for (int qb = 0; qb < QB; qb++) {   // the queries' offsets = their maxima over the first 32 keys (masked ones are -1e30; key 0 is always valid)
-        mask_half(sa[qb], 0, 0);
-        const float m0 = row_max(sa[qb]);
+    for (int qb = 0; qb < QB; qb++) {   // the queries' offsets = their maxima over their first 32 keys (masked ones are -1e30)
+        mask_half(sa[qb], 0, h_first);
+        float m0 = row_max(sa[qb]);
+        if (m0 < -1e29f) m0 = 0.0f;   // (role 2 with at most 32 keys: nothing valid in its half -- its P are exp2(-1e30) = 0, its O and l stay 0)
 #pragma unroll
         for (int g = 0; g < 16; g++) { negm[qb][g] = -m0; sa[qb][g] -= m0; }
     }
@@ -304,19 +363,27 @@ static __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
     using F_ = std::false_type;
     using H0 = std::integral_constant<int, 0>;
     using H1 = std::integral_constant<int, 1>;
-    int kt = 0;
-    for (; kt + 2 < nkt; kt++) {   // tiles whose successors are complete tiles: no masks
-        fast_half(sa, kt, fa, fb, H0{}, T_{}, F_{});
-        fast_half(sa, kt, fb, fa, H1{}, T_{}, F_{});
-    }
-    for (; kt < nkt; kt++) {   // the last one or two tiles
-        if (kt + 1 < nkt) {
-            fast_half(sa, kt, fa, fb, H0{}, T_{}, T_{});
-            fast_half(sa, kt, fb, fa, H1{}, T_{}, T_{});
-        } else {
-            fast_half(sa, kt, fa, fb, H0{}, F_{}, T_{});
-            fast_half(sa, kt, fb, fa, H1{}, F_{}, F_{});
+    if (!BAL || role == 0) {
+        int kt = 0;
+        for (; kt + 2 < nkt; kt++) {   // tiles whose successors are complete tiles: no masks
+            fast_half(sa, kt, fa, fb, H0{}, T_{}, F_{});
+            fast_half(sa, kt, fb, fa, H1{}, T_{}, F_{});
         }
+        for (; kt < nkt; kt++) {   // the last one or two tiles
+            if (kt + 1 < nkt) {
+                fast_half(sa, kt, fa, fb, H0{}, T_{}, T_{});
+                fast_half(sa, kt, fb, fa, H1{}, T_{}, T_{});
+            } else {
+                fast_half(sa, kt, fa, fb, H0{}, F_{}, T_{});
+                fast_half(sa, kt, fb, fa, H1{}, F_{}, F_{});
+            }
+        }
+    } else if (role == 1) {   // (one ring step per tile, like the whole-block waves: the barriers pair up)
+        for (int kt = 0; kt + 1 < nkt; kt++) half_only(sa[0], kt, H0{}, T_{});
+        half_only(sa[0], nkt - 1, H0{}, F_{});
+    } else {
+        for (int kt = 0; kt + 1 < nkt; kt++) half_only(sa[0], kt, H1{}, T_{});
+        half_only(sa[0], nkt - 1, H1{}, F_{});
     }
     // Did every probability stay in range?  A lane's row sum over its 16 keys of a half bounds each of them; 2^70 leaves 2^57 of fp32 headroom
     // for the sums over 4096 keys.  (The flag lives in the first bytes of the ring -- 5 x 16 KiB is exactly half a CU's LDS, two workgroups
@@ -350,6 +417,7 @@ static __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
             const unsigned vb = stage_of(gk) + v_lane;
 #pragma unroll 1
             for (int h = 0; h < 2; h++) {
+                if (BAL && role == 2) break;   // (waves 6 / 7 only move tiles and keep the barriers; blocks 4 / 5 are redone whole by waves 4 / 5)
                 bf16x8 kf[4];
                 qk_read(kf, gk, h);
 #pragma unroll
@@ -384,6 +452,32 @@ static __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
             }
         }
     }
+    if (BAL) {
+        // merge the key halves of blocks 4 / 5: waves 6 / 7 hand (offset, l, O) to waves 4 / 5 through LDS (the ring is idle), which bring both to the
+        // larger offset -- exact power-of-two factors <= 1 -- and add.  After a redo the whole-block result of waves 4 / 5 stands alone.
+        float* mbuf = reinterpret_cast<float*>(smem) + (size_t)(wave & 1) * 34 * 64;
+        __syncthreads();
+        if (role == 2 && !redo) {
+            mbuf[lane] = -negm[0][0];
+            mbuf[64 + lane] = lrun[0];
+#pragma unroll
+            for (int dt = 0; dt < 2; dt++)
+#pragma unroll
+                for (int g = 0; g < 16; g++) mbuf[(2 + dt * 16 + g) * 64 + lane] = oacc[0][dt][g];
+        }
+        __syncthreads();
+        if (role == 1 && !redo) {
+            const float off_a = -negm[0][0], off_b = mbuf[lane];
+            const float m = fmaxf(off_a, off_b);
+            const float fa_ = __builtin_amdgcn_exp2f(off_a - m), fb_ = __builtin_amdgcn_exp2f(off_b - m);
+            lrun[0] = lrun[0] * fa_ + mbuf[64 + lane] * fb_;
+#pragma unroll
+            for (int dt = 0; dt < 2; dt++)
+#pragma unroll
+                for (int g = 0; g < 16; g++) oacc[0][dt][g] = oacc[0][dt][g] * fa_ + mbuf[(2 + dt * 16 + g) * 64 + lane] * fb_;
+        }
+        if (role == 2) return;   // (no barrier after this point)
+    }
     if (STAMPS && st_on && lane == 0) { p.dbg[0] = st_acc[0]; p.dbg[1] = st_acc[1]; p.dbg[2] = st_acc[2]; p.dbg[3] = (unsigned long long)nkt; p.dbg[4] = st_acc[4]; p.dbg[5] = st_acc[5]; }
 #undef A3_STAMP
 
@@ -391,7 +485,7 @@ static __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
     for (int qb = 0; qb < QB; qb++) {
         const float ltot = lrun[qb] + __shfl_xor(lrun[qb], 32, 64);
         const float inv = 1.0f / ltot;
-        const int q = q0 + (wave * QB + qb) * 32 + fr;
+        const int q = q0 + (qblk + qb) * 32 + fr;
         if (q < len) {
             const size_t obase = (size_t)(row0 + q) * D + head * 64;
 #pragma unroll

@@ -1134,6 +1134,11 @@ int f5hip_cfm_sample(f5hip_dit* m, int32_t n_utt, const int32_t* dur, const floa
     return f5hip_cfm_sample_masked(m, n_utt, dur, nullptr, cond_dev, cond_mask, text, nt_max, y0_dev, t_grid, steps, cfg_strength, out_dev, stream);
 }
 
+int f5hip_set_attention_shape_invariant(int32_t on) {
+    f5_set_attn_shape_invariant(on);
+    return 0;
+}
+
 int f5hip_dit_set_ode_method(f5hip_dit* m, int32_t method) {
     if (!m) return fail(-1, "null model");
     if (method != 0 && method != 1) return fail(-1, "ode method %d: 0 = euler, 1 = midpoint", method);
