@@ -6,18 +6,35 @@
 #endif
 #include "gemm_launch.h"
 
-// Which attn3 instance: QB = 1 (32 queries per wave) with the tile height 32 NW, NW in {4, 6, 8}, that needs the fewest (rounds on the 256 CUs) x
-// (work per workgroup); ties -> the larger tile (fewer re-reads of K / V).  The grid is sized for the longest sequence; workgroups past a
-// shorter one's end exit at once.
-// QB = 2 (64 queries per wave, NW = 4, one wave per SIMD with the 512-register budget, every fragment read feeding two MFMAs) is built, parity-
-// tested (F5HIP_ATTN_QB=2 forces it) and NOT chosen: it measures 38.8 us against 35.4 at C2 and 225 against 186 at 16 x 1404
-// (profiles/r02_attn_bench.txt).  hipcc parks half of its score blocks in AGPRs (32 v_accvgpr_read per tile) and a lone in-order wave cannot
-// cover its own waits, which two independent waves per SIMD do for each other.
+// Which attn3 instance: the tile height 32 NW, NW in {4, 6, 8}, that needs the fewest (rounds on the 256 CUs) x (work per workgroup); ties -> the
+// larger tile (fewer re-reads of K / V).  The grid is sized for the longest sequence; workgroups past a shorter one's end exit at once.
+//   * 192-query tiles (NW = 6) run as the SIMD-balanced 8-wave kernel (attn3.h BAL): eight 240-register waves fill a CU, so it has the CU to
+//     itself and takes the 9-stage ring.  f5hip_set_attention_shape_invariant(1) keeps the 6-wave form, whose arithmetic is that of every
+//     other variant.
+//   * ring depth otherwise: a tile takes 2-4 us from beyond L2 into LDS and is consumed in ~1 us, so 3 tiles in flight (5 stages, 80 KiB: two
+//     workgroups per CU when the grid has more than one round) starve a LONE workgroup per CU -- 6- and 8-wave launches of at most 256
+//     workgroups get 9 stages (144 KiB, 7 tiles in flight); at NW = 4 the deep ring measured slower (16.8 vs 14.3 us at 2 x 748 x 12 heads).
+// -DF5HIP_EXPERIMENTS builds also carry QB = 2 (64 queries per wave, NW = 4, one wave per SIMD with the 512-register budget, every fragment read
+// feeding two MFMAs; F5HIP_ATTN_QB=2): parity-tested and measured slower -- 38.8 us against 35.4 at C2, 225 against 186 at 16 x 1404
+// (profiles/r02_attn_bench.txt): hipcc parks half of its score blocks in AGPRs (32 v_accvgpr_read per tile) and a lone in-order wave cannot
+// cover its own waits, which two waves per SIMD do for each other -- and F5HIP_ATTN_BAL=0 (the 6-wave form, for A/B timing).
 static int g_attn_shape_invariant = 0;   // f5hip_set_attention_shape_invariant
 void f5_set_attn_shape_invariant(int on) { g_attn_shape_invariant = on != 0; }
 
+template <bool SEG2>
+static void attn3_launch(const AttnArgs& a, int best, bool deep, bool bal, dim3 grid, hipStream_t st) {
+    if (bal) hipLaunchKernelGGL((attn3_fwd_kernel<8, SEG2, false, 9, 1, true>), grid, dim3(512), 0, st, a);
+    else if (best == 8 && deep) hipLaunchKernelGGL((attn3_fwd_kernel<8, SEG2, false, 9>), grid, dim3(512), 0, st, a);
+    else if (best == 8) hipLaunchKernelGGL((attn3_fwd_kernel<8, SEG2, false, 5>), grid, dim3(512), 0, st, a);
+    else if (best == 6 && deep) hipLaunchKernelGGL((attn3_fwd_kernel<6, SEG2, false, 9>), grid, dim3(384), 0, st, a);
+    else if (best == 6) hipLaunchKernelGGL((attn3_fwd_kernel<6, SEG2, false, 5>), grid, dim3(384), 0, st, a);
+    else hipLaunchKernelGGL((attn3_fwd_kernel<4, SEG2, false, 5>), grid, dim3(256), 0, st, a);
+}
+
 hipError_t f5_launch_attn3(const AttnArgs& a, int max_len, int heads, int n_seq, hipStream_t st) {
     if (a.seq_kv2_row0 && (!a.seq_kv_row0 || !a.seq_kv2_len)) return hipErrorInvalidValue;   // two key ranges per (pseudo-)sequence: MMDiT joint attention
+    bool no_bal = false;
+#ifdef F5HIP_EXPERIMENTS
     static const int force_qb = getenv("F5HIP_ATTN_QB") ? atoi(getenv("F5HIP_ATTN_QB")) : 0;
     if (force_qb == 2) {
         const dim3 grid((max_len + 255) / 256, heads, n_seq);
@@ -25,6 +42,9 @@ hipError_t f5_launch_attn3(const AttnArgs& a, int max_len, int heads, int n_seq,
         else hipLaunchKernelGGL((attn3_fwd_kernel<4, false, false, 9, 2>), grid, dim3(256), 0, st, a);
         return hipGetLastError();
     }
+    static const bool env_no_bal = getenv("F5HIP_ATTN_BAL") && atoi(getenv("F5HIP_ATTN_BAL")) == 0;
+    no_bal = env_no_bal;
+#endif
     int best = 8;
     long long best_cost = -1;
     for (int nw : {8, 6, 4}) {
@@ -33,23 +53,10 @@ hipError_t f5_launch_attn3(const AttnArgs& a, int max_len, int heads, int n_seq,
         if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = nw; }
     }
     const dim3 grid((max_len + 32 * best - 1) / (32 * best), heads, n_seq);
-    // Ring depth: a tile takes 2-4 us from beyond L2 into LDS and is consumed in ~1 us, so 3 tiles in flight (5 stages, 80 KiB: two workgroups
-    // per CU when the grid has more than one round) starve a LONE workgroup per CU -- that launch gets 9 stages (144 KiB, 7 tiles in flight).
-    const bool deep = best >= 6 && (long long)grid.x * grid.y * grid.z <= 256;   // (at NW = 4 the deep ring measured slower: 16.8 vs 14.3 us at 2 x 748 x 12 heads)
-    // 192-query tiles: the SIMD-balanced 8-wave form (attn3.h BAL) -- eight 240-register waves fill a CU, so it always has the CU to itself and takes
-    // the 9-stage ring; F5HIP_ATTN_BAL=0 or f5hip_set_attention_shape_invariant(1) keep the 6-wave form, whose arithmetic is that of every other variant
-    static const bool no_bal = getenv("F5HIP_ATTN_BAL") && atoi(getenv("F5HIP_ATTN_BAL")) == 0;
-    if (best == 6 && !no_bal && !g_attn_shape_invariant) {
-        if (a.seq_kv2_row0) hipLaunchKernelGGL((attn3_fwd_kernel<8, true, false, 9, 1, true>), grid, dim3(512), 0, st, a);
-        else hipLaunchKernelGGL((attn3_fwd_kernel<8, false, false, 9, 1, true>), grid, dim3(512), 0, st, a);
-        return hipGetLastError();
-    }
-#define A3_LAUNCH(NW_, SEG2_, NST_) hipLaunchKernelGGL((attn3_fwd_kernel<NW_, SEG2_, false, NST_>), grid, dim3(NW_ * 64), 0, st, a)
-#define A3_PICK(SEG2_, NST_) do { if (best == 8) A3_LAUNCH(8, SEG2_, NST_); else if (best == 6) A3_LAUNCH(6, SEG2_, NST_); else A3_LAUNCH(4, SEG2_, NST_); } while (0)
-    if (a.seq_kv2_row0) { if (deep) A3_PICK(true, 9); else A3_PICK(true, 5); }
-    else { if (deep) A3_PICK(false, 9); else A3_PICK(false, 5); }
-#undef A3_PICK
-#undef A3_LAUNCH
+    const bool deep = best >= 6 && (long long)grid.x * grid.y * grid.z <= 256;
+    const bool bal = best == 6 && !no_bal && !g_attn_shape_invariant;
+    if (a.seq_kv2_row0) attn3_launch<true>(a, best, deep, bal, grid, st);
+    else attn3_launch<false>(a, best, deep, bal, grid, st);
     return hipGetLastError();
 }
 
