@@ -186,7 +186,10 @@ def test_layernorm_unit_op(rms):
                                                   ((64,), (1,), 2, 1.0), ((2341, 2341), None, 16, 1.0), ((33,), (33,), 2, 1.0), ((97, 160), (40, 129), 2, 1.0),
                                                   ((1404, 300), (1404, 290), 4, 12.0), ((200,), None, 2, 40.0),
                                                   # 6-wave workgroups with the 9-stage ring (one barrier per two tiles) next to sequences of 2 / 3 / 3 / 5 tiles
-                                                  ((1404, 70, 130, 200), (1404, 65, 130, 129), 8, 1.0), ((1404, 320, 130, 200), (1404, 300, 130, 129), 8, 12.0)])
+                                                  ((1404, 70, 130, 200), (1404, 65, 130, 129), 8, 1.0), ((1404, 320, 130, 200), (1404, 300, 130, 129), 8, 12.0),
+                                                  # the balanced 8-wave kernel with key counts inside the first half tile (its key-half waves 6 / 7 then own nothing
+                                                  # valid), just past it, and one key; the last one also through the running-maximum redo
+                                                  ((1404, 1404), (1404, 20), 16, 1.0), ((1404, 1404), (33, 1), 16, 1.0), ((1500, 1310), (47, 1310), 16, 12.0)])
 def test_attention_unit_op(impl, lens, kv, heads, k_gain):
     """Attention kernel alone vs fp64 softmax attention on the bf16-rounded operands (q after the log2(e) / 8 scale, undone in fp64), incl. the key-padding mask
     (F/model/modules.py:429-434), ragged sequences, tiles that overhang a sequence, key counts that end inside either half of a 64-key tile,
