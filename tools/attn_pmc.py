@@ -2,7 +2,7 @@
 """A few launches of the attention kernel at the C2 / C3 shapes for rocprofv3 --pmc collection (diagnostics):
   rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES \
             SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d gpurun_out/pmc_attn -o a -- python3 tools/attn_pmc.py
-then `python tools/attn_pmc.py --summarise gpurun_out/pmc_attn` prints per-kernel means."""
+then `python tools/attn_pmc.py --summarise gpurun_out/pmc_attn [kernel-name substring, default attn3]` prints per-kernel means."""
 import csv
 import glob
 import os
@@ -14,7 +14,7 @@ if len(sys.argv) > 2 and sys.argv[1] == "--summarise":
     for f in files:
         for r in csv.DictReader(open(f)):
             k = r.get("Kernel_Name", "")
-            if "attn3" not in k:
+            if (sys.argv[3] if len(sys.argv) > 3 else "attn3") not in k:
                 continue
             key = (k.split("(")[0][-60:], r["Grid_Size"], r["Counter_Name"])
             a = acc.setdefault(key, [0, 0.0])
