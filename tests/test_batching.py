@@ -117,6 +117,79 @@ def test_micro_batcher_batches_concurrent_requests_and_isolates_failures():
         mb.submit("late")
 
 
+def test_micro_batcher_close_under_load_resolves_every_future():
+    """requests queued when close() is called are served (they were accepted), nothing lands behind the shutdown mark, a late
+    submit is refused, and no future is left unresolved."""
+    gate = threading.Event()
+
+    def run(batch):
+        gate.wait(timeout=10)
+        return [r * 2 for r in batch]
+
+    mb = serve.MicroBatcher(run, max_requests=2, max_wait_ms=1)
+    futs = [mb.submit(i) for i in range(7)]
+    closer = threading.Thread(target=mb.close)
+    closer.start()
+    time.sleep(0.05)
+    with pytest.raises(RuntimeError):
+        mb.submit(99)                    # refused as soon as close() has been entered, while batches are still running
+    gate.set()
+    closer.join(timeout=20)
+    assert not closer.is_alive()
+    assert [f.result(timeout=1) for f in futs] == [i * 2 for i in range(7)]
+    # a worker thread that is gone: pending items are failed, not stranded
+    mb2 = serve.MicroBatcher(lambda b: b, max_requests=2, max_wait_ms=1)
+    mb2.close()
+    mb2._q.put(("stranded", fut := serve.Future()))
+    mb2._fail_pending()
+    with pytest.raises(RuntimeError, match="closed"):
+        fut.result(timeout=1)
+
+
+def test_manager_without_batcher_serialises_the_device_path(tmp_path):
+    """the routes run in a thread pool; with the default TTSManager() (no micro_batch) concurrent requests must still
+    enter the model object one at a time -- the library allows one call in flight per handle."""
+    class Probe(UnitModel):
+        def __init__(self):
+            super().__init__()
+            self.inside, self.max_inside = 0, 0
+            self.lock = threading.Lock()
+
+        def sample_units(self, *a, **k):
+            with self.lock:
+                self.inside += 1
+                self.max_inside = max(self.max_inside, self.inside)
+            time.sleep(0.03)
+            try:
+                return super().sample_units(*a, **k)
+            finally:
+                with self.lock:
+                    self.inside -= 1
+
+    from fastapi.testclient import TestClient
+    reg = serve.VoiceRegistry()
+    reg.add("KAN_F (Happy)", _wav(tmp_path, "a.wav", 200), "reference words")
+    model = Probe()
+    mgr = serve.TTSManager(nfe_step=4).load(model, Vocoder())
+    c = TestClient(serve.create_app(mgr, reg))
+    out = [None] * 6
+
+    def post(i):
+        out[i] = c.post("/v1/audio/speech", json={"text": f"request {i} speaks."})
+
+    th = [threading.Thread(target=post, args=(i,)) for i in range(6)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=60)
+    assert all(r is not None and r.status_code == 200 for r in out)
+    assert len(model.batches) == 6 and model.max_inside == 1
+    mgr.close()
+    assert mgr.model is None
+    with pytest.raises(ValueError):
+        mgr.synthesize("x", ref_audio_path="a", ref_text="b")
+
+
 def _wav(tmp_path, name, freq):
     x = (6000 * np.sin(2 * np.pi * freq * np.arange(24000 * 3) / 24000)).astype(np.int16)
     p = tmp_path / name
@@ -196,3 +269,67 @@ def test_sharded_sampler_gloo_world2_equals_single_process():
     assert res[0][0] is True                                  # rank 0: sharded == single-process, twice
     assert res[1][0] == 2                                     # rank 1 took part in both jobs, then was released
     assert sum(res[0][1]) > 0 and sum(res[1][1]) > 0          # both ranks sampled units
+
+
+class FailingOnRank1(UnitModel):
+    def sample_units(self, audio, units, **k):
+        if dist.get_rank() == 1:
+            raise RuntimeError("device fault on rank 1")
+        return super().sample_units(audio, units, **k)
+
+
+def _rank_fail(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    from tts_indic_server_f5_amd import infer as I, serve as S
+    local = FailingOnRank1()
+    if rank != 0:
+        n = S.rank_worker_loop(local)            # the failing job is reported through its gather; the loop survives it
+        q.put((rank, n))
+    else:
+        sh = S.ShardedSampler(local)
+        a = _clip(200.0)
+        reqs = [(a, "first voice words", LONG), (a, "first voice words", LONG + " And more.")]
+        mb = S.MicroBatcher(lambda rs: [w for w, _, _ in I.infer_requests(rs, sh, Vocoder(), nfe_step=4)], max_requests=4, max_wait_ms=200)
+        futs = [mb.submit(r) for r in reqs]
+        kinds = []
+        for f in futs:
+            try:
+                f.result(timeout=60)
+                kinds.append("ok")
+            except S.ShardedJobError as e:
+                kinds.append("sharded:" + str(e))
+            except Exception as e:   # noqa: BLE001
+                kinds.append("other:" + repr(e))
+        refused = False
+        try:
+            sh.sample_units(a[0], [(["x"], 10)], steps=4, cfg_strength=2.0, sway_sampling_coef=-1.0)
+        except S.ShardedJobError:
+            refused = True                        # no second job on a backend in an unknown state (and no new collective)
+        mb.close()
+        sh.close()
+        q.put((rank, (kinds, list(mb.batch_sizes), refused)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_job_failure_on_one_rank_fails_the_batch_and_nobody_hangs():
+    """a rank whose sampler raises still joins the job's gather; rank 0 raises ShardedJobError after the collective,
+    MicroBatcher fails the whole batch WITHOUT per-request retries (a retry would issue a new broadcast against a backend in an unknown
+    state), the sampler refuses later jobs, and the worker loop is released normally."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rank_fail, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    kinds, sizes, refused = res[0]
+    assert len(kinds) == 2 and all(k.startswith("sharded:") and "rank(s) [1]" in k for k in kinds), kinds
+    assert sizes == [2] and refused                            # one batch, no per-request retry
+    assert res[1] == 1                                         # the worker took part in exactly that job and was then released

@@ -132,10 +132,9 @@ UTINY = dict(dim=128, depth=4, heads=2, ff_mult=4, text_num_embeds=40)
 
 @pytest.mark.parametrize("planes", [2, 3], ids=["bf16x3", "mixed_f16"])
 def test_unett_tiny_vs_reference_fixture(golden_dir, planes):
-    """Tolerance: 1e-3 for the forwards; for the 8-step sample 1e-3 x the output rms (1.49) like every UNetT sample test -- the
-    un-gated residual stream puts the output rms above 1.  This tiny model sits at 9.5e-4 already in the strict split-bf16 mode
-    (its error is not GEMM precision: fp16 block GEMMs add 1.1e-4), which is why the unscaled bound cannot be its criterion;
-    the real configuration, E2-Base at N = 2340, is inside the unscaled 1e-3 in both modes (tests/test_gpu_configs.py, C5)."""
+    """The reference's own tiny UNetT (forward in both CFG branches, 8-step CFM.sample) at north_star's plain 1e-3.  With bf16 attention
+    operands this fixture sat at 1.03e-3 / 1.11e-3 (tools/attn_ladder.py: 9.7e-4 of it from the bf16 Q / K / P / V alone); the fp16
+    operands of round 3 bring it to the level of the GEMM mode."""
     from tts_indic_server_f5_amd.model import F5HipModel, UNetTArch
     g = _load(golden_dir, "unett_tiny")
     m = F5HipModel(UNetTArch(**UTINY), synth.unett_state_dict(**UTINY), gemm_planes=planes)
@@ -144,7 +143,7 @@ def test_unett_tiny_vs_reference_fixture(golden_dir, planes):
         assert _report("unett tiny forward " + tag, out, g["out_" + tag]) < 1e-3
     out, _ = m.sample(g["cond"][:, :15], g["text"], 45, steps=8, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=9)
     ref = g["sample_out"][:, 15:]
-    assert _report("unett tiny sample", out[:, 15:], ref) < 1e-3 * max(1.0, ref.pow(2).mean().sqrt().item())
+    assert _report("unett tiny sample", out[:, 15:], ref) < 1e-3
     assert torch.equal(out[:, :15].cpu(), g["sample_out"][:, :15])
 
 
@@ -155,8 +154,7 @@ def test_unett_small_forward_vs_reference_fixture(golden_dir, planes):
     m = F5HipModel(E2TTS_SMALL, synth.unett_state_dict(dim=768, depth=20, heads=12), gemm_planes=planes)
     out = m.transformer_forward(g["x"], g["cond"], g["text"], 0.5, False, False)
     ref = g["out_cond"]
-    e = _report("unett small forward", out, ref)
-    assert e < 1e-3 * max(1.0, ref.pow(2).mean().sqrt().item())   # un-gated residual stream: output rms is > 1
+    assert _report("unett small forward", out, ref) < 1e-3
 
 
 # ---------------------------------------------------------------- MMDiT, F/model/backbones/mmdit.py
@@ -182,7 +180,7 @@ def test_mmdit_tiny_vs_reference_fixture(golden_dir, planes):
     assert _report("mmdit tiny audio stream behind block 0", hx, g["block0_x"]) < 1e-3
     out, _ = m.sample(g["sample_cond"], g["sample_text"], 48, steps=8, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=7)
     ref = g["sample_out"][:, 20:]
-    assert _report("mmdit tiny sample", out[:, 20:], ref) < 1e-3 * max(1.0, ref.pow(2).mean().sqrt().item())
+    assert _report("mmdit tiny sample", out[:, 20:], ref) < 1e-3
     assert torch.equal(out[:, :20].cpu(), g["sample_out"][:, :20])
 
 
@@ -256,9 +254,13 @@ def test_argument_errors_are_reported_not_faulted(tiny_model):
 def test_batch_of_copies_equals_single(base_model, attn_shape_invariant):
     """Size-independent property at the batch-mode shapes (M = 8 x 1408 rows: the wide-tile GEMM path): a batch of identical utterances
     with identical noise gives, item by item, the batch-1 result (only the fp32 summation order of the GEMM tiles may differ) -- with the
-    shape-invariant attention arithmetic.  In the default mode the single utterance runs the SIMD-balanced attention kernel, which associates
-    the sums of a third of its query blocks differently: the two results then differ by the bf16 rounding noise of the probabilities,
-    measured 1.2e-4 (bf16x3) / 6.0e-4 (mixed) rms after these two steps -- asserted below at 1.5e-3, the size of a real indexing bug being O(1)."""
+    shape-invariant attention arithmetic.  In the default mode the single utterance runs the SIMD-balanced attention kernel, which sums the
+    two key halves of a third of its query blocks separately: same offsets (attn3.h sample keys), same fp16 probabilities, another fp32
+    association -- a last-bit difference.  In split-bf16 mode it stays one (2e-5 after these two steps; 1.2e-4 in round 2, with bf16
+    probabilities and per-half offsets).  In mixed mode ANY last-bit difference grows to the mode's own noise floor within a few blocks,
+    because it flips fp16 roundings of the next GEMM's operands (profiles/r03_attn_mode_tapdiff.txt: a 2^-24 perturbation of the INPUT,
+    with identical attention kernels, grows the same way): two runs are two draws of the same 4e-4 rounding noise and differ by ~sqrt(2)
+    of it.  Hence the per-mode bounds below; serving paths that promise batch-independent results run shape-invariant (serve.TTSManager)."""
     gc = torch.Generator().manual_seed(14)
     cond = torch.randn(1, 469, 100, generator=gc)
     text = synth.text_ids()
@@ -271,4 +273,8 @@ def test_batch_of_copies_equals_single(base_model, attn_shape_invariant):
     from tts_indic_server_f5_amd import _lib
     _lib.check(_lib.lib().f5hip_set_attention_shape_invariant(0), "set_attention_shape_invariant")
     fast, _ = base_model.sample(cond, text, 1404, steps=2, cfg_strength=2.0, sway_sampling_coef=-1.0, y0=y0)
-    assert _report("default (balanced) attention vs shape-invariant, single utterance", fast[0], one[0]) < 1.5e-3
+    bound = 1e-4 if base_model.gemm_planes == 2 else 1e-3
+    assert _report("default (balanced) attention vs shape-invariant, single utterance", fast[0], one[0]) < bound
+    four_d, _ = base_model.sample(cond.expand(4, -1, -1), text.expand(4, -1), 1404, steps=2, cfg_strength=2.0, sway_sampling_coef=-1.0,
+                                  y0=y0.expand(4, -1, -1))
+    assert _report("default mode: item of a batch vs the same utterance alone", four_d[2], fast[0]) < bound

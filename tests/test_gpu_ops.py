@@ -136,7 +136,7 @@ def test_gemm_f16_output_saturates():
 @pytest.mark.parametrize("M,D,prec", [(2816, 1024, 3), (1404, 1024, 3), (1536, 768, 3), (2816, 1024, 2), (300, 256, 2)])
 def test_qkv_unit_op(M, D, prec):
     """Fused QKV projection + epilogue against a reference that applies x-transformers' interleaved rotary embedding to channels
-    0..63 of q and k (head 0 only: F/model/modules.py:414-426), scales q by log2(e) / 8 (the attention kernel works in base-2 exponents) and rounds to bf16 like the kernel's outputs."""
+    0..63 of q and k (head 0 only: F/model/modules.py:414-426), scales q by log2(e) / 8 (the attention kernel works in base-2 exponents) and rounds to fp16 like the kernel's outputs."""
     from oracle import dit_oracle as O
     from tts_indic_server_f5_amd import ops
     g = torch.Generator().manual_seed(M + D + prec)
@@ -155,11 +155,11 @@ def test_qkv_unit_op(M, D, prec):
     if prec == 3 and M == 2816:
         assert _counter("gemm5_wide") == 1 and _counter("gemm5_rb11") == 1
     for name, got, ref in (("q", gq, q), ("k", gk, k), ("v", gv, v)):
-        err = (got.cpu() - ref.bfloat16().float()).abs()
-        # bf16 outputs: identical up to accumulation-order flips of the last bf16 bit on a few elements
-        assert err.max() <= 2.0 ** -7 * ref.abs().max(), name
-        assert (err > 0).float().mean() < 0.02, name
-        assert _rel(got, ref.double()) < 3e-3, name
+        err = (got.cpu() - ref.half().float()).abs()
+        # fp16 outputs: identical up to accumulation-order flips of the last fp16 bit on some elements
+        assert err.max() <= 2.0 ** -10 * ref.abs().max(), name
+        assert (err > 0).float().mean() < 0.10, name
+        assert _rel(got, ref.double()) < 4e-4, name
 
 
 @pytest.mark.parametrize("rms", [False, True])
@@ -191,10 +191,11 @@ def test_layernorm_unit_op(rms):
                                                   # valid), just past it, and one key; the last one also through the running-maximum redo
                                                   ((1404, 1404), (1404, 20), 16, 1.0), ((1404, 1404), (33, 1), 16, 1.0), ((1500, 1310), (47, 1310), 16, 12.0)])
 def test_attention_unit_op(impl, lens, kv, heads, k_gain):
-    """Attention kernel alone vs fp64 softmax attention on the bf16-rounded operands (q after the log2(e) / 8 scale, undone in fp64), incl. the key-padding mask
+    """Attention kernel alone vs fp64 softmax attention on the fp16-rounded operands (q after the log2(e) / 8 scale, undone in fp64), incl. the key-padding mask
     (F/model/modules.py:429-434), ragged sequences, tiles that overhang a sequence, key counts that end inside either half of a 64-key tile,
-    and the C2 / C1 / C5 shapes.  k_gain > 1 multiplies the keys from position 40 on: logits tens to hundreds of nats above each query's
-    maximum over its first 32 keys, which is what sends a workgroup of attn3 from its fixed-offset fast loop to the running-maximum redo."""
+    and the C2 / C1 / C5 shapes.  k_gain > 1 multiplies every key at a position = 7 mod 16 from position 40 on (never one of a query block's
+    sample keys, csrc/attn3.h): logits tens to hundreds of nats above each query's maximum over its sample, which is what sends a workgroup
+    of attn3 from its fixed-offset fast loop to the running-maximum redo."""
     from tts_indic_server_f5_amd import ops
     g = torch.Generator().manual_seed(sum(lens) + heads)
     n, D = sum(lens), 64 * heads
@@ -204,10 +205,10 @@ def test_attention_unit_op(impl, lens, kv, heads, k_gain):
     if k_gain != 1.0:
         o = 0
         for L in lens:
-            k[o + 40:o + L] *= k_gain
+            k[o + 47:o + L:16] *= k_gain
             o += L
     out, _ = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), lens, kv, heads=heads, impl=impl)
-    qb, kb, vb = (q * Q_SCALE).bfloat16().double() * math.log(2.0), k.bfloat16().double(), v.bfloat16().double()
+    qb, kb, vb = (q * Q_SCALE).half().double() * math.log(2.0), k.half().double(), v.half().double()
     o, refs = 0, []
     for i, L in enumerate(lens):
         kl = L if kv is None else kv[i]
@@ -217,10 +218,12 @@ def test_attention_unit_op(impl, lens, kv, heads, k_gain):
         refs.append((torch.softmax(s, dim=-1) @ vs).transpose(0, 1).reshape(L, D))
         o += L
     ref = torch.cat(refs)
-    # P is rounded to bf16 before the P V product (8 mantissa bits on probabilities <= 1); the output planes carry 16 bits
+    # P is rounded to fp16 before the P V product (11 significand bits); the output planes carry 16 bits
     assert torch.isfinite(out).all()
-    assert (out.double().cpu() - ref).abs().max().item() < 2e-2
-    assert _rel(out, ref) < 4e-3
+    err, rel = (out.double().cpu() - ref).abs().max().item(), _rel(out, ref)
+    print(f"[parity] attention lens {lens} kv {kv} heads {heads} k_gain {k_gain}: max err {err:.3e} rel rms {rel:.3e}")
+    assert err < 2.5e-3
+    assert rel < 5e-4
 
 
 # ---------------------------------------------------------------------------------------------------------------- conv1d (BigVGAN convolutions)
@@ -276,7 +279,7 @@ def test_joint_attention_vs_torch(x_len, c_len, x_kv):
     Fx, Fc = sum(x_len), sum(c_len)
     q, k, v = (torch.randn(Fx + Fc, D, generator=g) for _ in range(3))
     out = ops.joint_attention(q.to(DEV), k.to(DEV), v.to(DEV), x_len, c_len, x_kv, heads=heads).cpu()
-    bf = lambda t: t.to(torch.bfloat16).double()
+    bf = lambda t: t.to(torch.float16).double()
     ox, oc = 0, Fx
     worst = 0.0
     for i, (n, nt) in enumerate(zip(x_len, c_len)):
@@ -293,12 +296,12 @@ def test_joint_attention_vs_torch(x_len, c_len, x_kv):
         worst = max(worst, err)
         ox += n; oc += nt
     print(f"[parity] joint attention x {x_len} c {c_len} kv {x_kv}: max err {worst:.3e}")
-    assert worst < 2e-2   # bf16 P and V operands (8 mantissa bits) over up to ~1.6 k keys; the single-range test uses the same bound
+    assert worst < 2.5e-3   # fp16 P and V operands (11 significand bits) over up to ~1.6 k keys; the single-range test uses the same bound
 
 
 def test_attention_random_shapes(monkeypatch):
     """tools/attn_fuzz.py with a fixed seed: 24 random ragged batches (1-16 heads, key counts ending anywhere in a tile, a third of them with
-    logits far above the first key block) + 6 two-range cases, each against fp64 attention on the rounded operands, bound 2e-2 as above."""
+    logits far above the first key block) + 6 two-range cases, each against fp64 attention on the rounded operands, bound 2.5e-3 as above."""
     import importlib.util
     import os
     import sys

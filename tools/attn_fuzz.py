@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Randomised shapes for the attention kernel against fp64 softmax attention on the bf16-rounded operands (same reference and bounds as
+"""Randomised shapes for the attention kernel against fp64 softmax attention on the fp16-rounded operands (same reference and bounds as
 tests/test_gpu_ops.py::test_attention_unit_op): ragged batches, key counts ending anywhere in a tile, 1-16 heads, occasional large logits
 (the running-maximum redo), and the two-range (joint) kernels.  Usage: python tools/attn_fuzz.py [n_cases] [seed]"""
 import math
@@ -49,7 +49,7 @@ def main():
                 o += L
         out, _ = ops.attention(q.cuda(), k.cuda(), v.cuda(), lens, kv, heads=heads, impl=3)
         out = out.double().cpu()
-        qb, kb, vb = (q * QS).bfloat16().double() * LN2, k.bfloat16().double(), v.bfloat16().double()
+        qb, kb, vb = (q * QS).half().double() * LN2, k.half().double(), v.half().double()
         o, err = 0, 0.0
         for L, kl in zip(lens, kv):
             ok = torch.arange(L) < kl
@@ -57,7 +57,7 @@ def main():
             err = max(err, (out[o:o + L] - r).abs().max().item())
             o += L
         worst = max(worst, err)
-        flag = "" if (err < 2e-2 and torch.isfinite(out).all()) else "   <-- FAIL"
+        flag = "" if (err < 2.5e-3 and torch.isfinite(out).all()) else "   <-- FAIL"
         print(f"case {case:3d}: heads {heads:2d} lens {lens} kv {kv} gain {gain:4.1f}: max err {err:.3e}{flag}", flush=True)
         if flag:
             sys.exit(1)
@@ -72,7 +72,7 @@ def main():
         Fx, Fc, D = sum(x_len), sum(c_len), 64 * heads
         q, k, v = (torch.randn(Fx + Fc, D, generator=g) for _ in range(3))
         out = ops.joint_attention(q.cuda(), k.cuda(), v.cuda(), x_len, c_len, x_kv, heads=heads).double().cpu()
-        bf = lambda t: t.to(torch.bfloat16).double()
+        bf = lambda t: t.to(torch.float16).double()
         ox, oc, err = 0, Fx, 0.0
         for n, nt, kvn in zip(x_len, c_len, x_kv):
             sel = torch.cat([torch.arange(ox, ox + n), torch.arange(oc, oc + nt)])
@@ -81,11 +81,11 @@ def main():
             err = max(err, (out[sel] - r).abs().max().item())
             ox += n; oc += nt
         worst = max(worst, err)
-        flag = "" if (err < 2e-2 and torch.isfinite(out).all()) else "   <-- FAIL"
+        flag = "" if (err < 2.5e-3 and torch.isfinite(out).all()) else "   <-- FAIL"
         print(f"joint {case:3d}: heads {heads} x {x_len} c {c_len} kv {x_kv}: max err {err:.3e}{flag}", flush=True)
         if flag:
             sys.exit(1)
-    print(f"all cases within 2e-2 (worst {worst:.3e})")
+    print(f"all cases within 2.5e-3 (worst {worst:.3e})")
 
 
 if __name__ == "__main__":

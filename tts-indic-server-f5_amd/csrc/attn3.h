@@ -26,16 +26,28 @@
 // SEG2: the keys are two row ranges (AttnArgs::seq_kv_row0 / seq_kv2_*): tile kt covers 64 rows of the first range while kt < nkt1, of the
 // second after it; the last tile of EACH range is masked.  SEG2 = false is the single-range kernel of the DiT / UNetT path.
 //
+// Operands are FP16 (round 3): q (pre-scaled), k, v^T arrive as saturated fp16 from the QKV epilogue and exp(S) is rounded to fp16 for the
+// P V product -- v_mfma_f32_32x32x16_f16 issues at the bf16 rate and carries 11 significand bits instead of 8.  tools/attn_ladder.py: on the
+// reference's tiny UNetT / MMDiT CFM.sample fixtures bf16 attention operands alone cost 9.7e-4 / 1.08e-3 rms (above north_star's 1e-3),
+// fp16 ones 1.2e-4 / 1.4e-4; they were also what made a request's result depend on the batch it ran in.
+//
 // Softmax with a FIXED per-query offset folded into the score MFMAs.  q arrives scaled by log2(e) / 8 (F5_Q_SCALE), so a score is already
-// a base-2 exponent.  Floating point is scale-invariant: the running maximum of online softmax only has to keep exp2 inside the fp32
-// range, it does not have to be the maximum.  So the offset of a query is its row maximum over the FIRST 32 keys and stays put: the first
-// MFMA of every later score block takes C = splat(-off) instead of 0, the accumulator leaves the matrix pipe as s - off, and exp2 applies
-// to it directly -- per score one exp2, one add, half a convert; no max, no subtract, no scale, no rescaling of O, no branch.  Whether every
-// probability stayed in range is decided ONCE, after the loop, from the largest row sum a lane saw (one v_max per half tile): if one did
-// not (needs a logit 48 nats above the query's maximum over its first 32 keys), the WHOLE workgroup redoes its tile with a plain
-// running-maximum loop -- correct for any input, and exercised by tests/test_gpu_ops.py (k_gain cases).
+// a base-2 exponent.  Floating point is scale-invariant: the running maximum of online softmax only has to keep exp2 inside the range of
+// the P operand, it does not have to be the maximum.  So the offset of a query is fixed BEFORE the loop: A3_OFF_MARGIN above its maximum score
+// over 32 SAMPLE keys (16 spread over the whole key range, 16 around the query block's own position -- neighbouring frames are where a
+// speech model's attention peaks) and stays put: the first MFMA of every score block takes C = splat(-off) instead of 0, the accumulator
+// leaves the matrix pipe as s - off, and exp2 applies to it directly -- per score one exp2, one add, half a convert; no max, no subtract,
+// no scale, no rescaling of O, no branch.  fp16 normals span 2^-14 .. 2^16: with the offset 2 binades above the sample maximum the sampled
+// keys have P <= 1/4, the true row maximum has P >= 1/4 (samples are keys), and every P within 2^-12 of it is still a normal number.
+// Whether every probability stayed below fp16's largest finite value is decided ONCE, after the loop, from the largest row sum a lane saw
+// (one v_max per half tile; an inf that an overflowing P put into O is discarded with it): if one did not -- a logit more than 17 binades
+// = 11.8 nats above the query's maximum over its sample -- the WHOLE workgroup redoes its tile with a plain running-maximum loop, correct
+// for any input and exercised by tests/test_gpu_ops.py (k_gain cases).  Because every variant of the kernel (and both key halves of a BAL
+// block) derives the offset from the same sample, variants differ only in the association of fp32 sums.
 // (The running-maximum formulation in the hot loop measured 45.7 us at C2 against 41.4 us for the fixed offset, before any of the
 // scheduling work.)
+#define A3_OFF_MARGIN 2.0f
+#define A3_P_LIMIT 0x1p15f
 // BAL (NW = 8, QB = 1, 192 queries per workgroup): the SIMD-balanced form of the 6-block tile.  Eight waves put two on every SIMD; waves 0-3 own a
 // query block each over all keys, waves 4 / 5 own blocks 4 / 5 over keys 0-31 of every tile and waves 6 / 7 the SAME blocks over keys 32-63,
 // so every SIMD carries three half tiles per tile (with six whole-block waves two SIMDs carry four and two carry two, and the per-tile barrier
@@ -75,17 +87,28 @@ static __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
 
     // queries of this wave (rows beyond the sequence stay inside its 128-row padding or the next sequence: finite data, never stored).
     // q0 + QT - 1 can exceed the padded rows of the LAST sequence only by < 256 rows: the workspace has that much slack.
-    bf16x8 qf[QB][4];
+    f16x8 qf[QB][4];
 #pragma unroll
     for (int qb = 0; qb < QB; qb++) {
         const __bf16* qrow = p.qk + (size_t)(row0 + q0 + (qblk + qb) * 32 + fr) * (2 * D) + head * 64 + fh * 8;
 #pragma unroll
-        for (int s = 0; s < 4; s++) qf[qb][s] = *reinterpret_cast<const bf16x8*>(qrow + s * 16);
+        for (int s = 0; s < 4; s++) qf[qb][s] = *reinterpret_cast<const f16x8*>(qrow + s * 16);
     }
-    // Retire the Q loads BEFORE the first LDS-DMA is issued: with a DMA in flight hipcc can only wait vmcnt(0) for an
+    // The 32 SAMPLE keys that fix the softmax offsets of this wave's queries (below): 16 spread evenly over the (first) key range and 16 at
+    // every second position (every fourth at QB = 2) of the wave's own query block, clamped into the range -- all of them valid keys.  Their K
+    // rows come straight from global memory in the fragment layout of a score MFMA's A operand (lane = key fr, 8 features per k-step).
+    f16x8 ksamp[4];
+    {
+        const int sidx = fr < 16 ? (fr * kvlen) >> 4 : min(q0 + qblk * 32 + (fr - 16) * 2 * QB, kvlen - 1);
+        const __bf16* krow = p.qk + (size_t)(kv_row0 + sidx) * (2 * D) + D + head * 64 + fh * 8;
+#pragma unroll
+        for (int s = 0; s < 4; s++) ksamp[s] = *reinterpret_cast<const f16x8*>(krow + s * 16);
+    }
+    // Retire the Q / sample loads BEFORE the first LDS-DMA is issued: with a DMA in flight hipcc can only wait vmcnt(0) for an
     // ordinary VGPR load, and it would put that wait inside the KV loop, draining the ring every tile.
 #pragma unroll
     for (int qb = 0; qb < QB; qb++) asm volatile("" ::"v"(qf[qb][0]), "v"(qf[qb][1]), "v"(qf[qb][2]), "v"(qf[qb][3]) : "memory");
+    asm volatile("" ::"v"(ksamp[0]), "v"(ksamp[1]), "v"(ksamp[2]), "v"(ksamp[3]) : "memory");
 
     // LDS-DMA: a KV tile is 8 K pieces + 8 V^T pieces of 1 KiB (8 rows x 128 B); wave w moves pieces w, w + NW, ... (0-7 = K, 8-15 = V^T).
     // Physical 16-B slot (lane & 7) of row r holds logical chunk (lane & 7) ^ ((r >> 1) & 7)  (same swizzle as the fragment reads).
@@ -157,21 +180,21 @@ static __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
     const unsigned k_lane = (unsigned)(fr * 128 + ((fh ^ ((fr >> 1) & 7)) << 4));
     const unsigned v_lane = k_lane + 8192u;
     auto stage_of = [&](int kt) { return (unsigned)((kt % NST) * STAGE); };
-    auto qk_read = [&](bf16x8 (&kf)[4], int kt, int h) {
+    auto qk_read = [&](f16x8 (&kf)[4], int kt, int h) {
         const unsigned kb = stage_of(kt) + k_lane;
 #pragma unroll
-        for (int sI = 0; sI < 4; sI++) kf[sI] = *reinterpret_cast<const bf16x8*>(smem + (kb ^ (unsigned)(sI << 5)) + h * 4096);
+        for (int sI = 0; sI < 4; sI++) kf[sI] = *reinterpret_cast<const f16x8*>(smem + (kb ^ (unsigned)(sI << 5)) + h * 4096);
     };
     // S^T block = K_half Q^T - offset (four chained MFMAs; C of the first = negm)
-    auto qk_mfma = [&](f32x16& s, const bf16x8 (&kf)[4], int qb) {
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[qb][0], negm[qb], 0, 0, 0);
+    auto qk_mfma = [&](f32x16& s, const f16x8 (&kf)[4], int qb) {
+        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[0], qf[qb][0], negm[qb], 0, 0, 0);
 #pragma unroll
-        for (int sI = 1; sI < 4; sI++) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[sI], qf[qb][sI], s, 0, 0, 0);
+        for (int sI = 1; sI < 4; sI++) s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[sI], qf[qb][sI], s, 0, 0, 0);
     };
     // V^T fragments of k-step s2 of key half h (16 keys, stored in vt_col order: a lane's 8 keys are contiguous): one 16-byte read per 32 features
-    auto v_read = [&](bf16x8 (&vf)[2], unsigned vb, int h, int s2) {
+    auto v_read = [&](f16x8 (&vf)[2], unsigned vb, int h, int s2) {
 #pragma unroll
-        for (int dt = 0; dt < 2; dt++) vf[dt] = *reinterpret_cast<const bf16x8*>(smem + (vb ^ (unsigned)((h * 2 + s2) << 5)) + dt * 4096);
+        for (int dt = 0; dt < 2; dt++) vf[dt] = *reinterpret_cast<const f16x8*>(smem + (vb ^ (unsigned)((h * 2 + s2) << 5)) + dt * 4096);
     };
     // key-padding mask of half h of tile kt (only the last tile of a key range is partial)
     auto mask_half = [&](f32x16& s, int kt, int h) {
@@ -223,7 +246,7 @@ static __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
     // H: which half of tile kt `sc` holds.  The block produced here is (kt, 1) for H = 0 and (kt + 1, 0) for H = 1.
     // NEXT_TILE: tile kt + 1 exists.  MASK: the score block produced here belongs to a possibly partial tile.
     float rs_max = 0.0f;
-    struct Frags { bf16x8 k[4]; bf16x8 v[2][2]; };
+    struct Frags { f16x8 k[4]; f16x8 v[2][2]; };
     auto fast_half = [&](f32x16 (&sc)[QB], int kt, Frags& use, Frags& fill, auto h_t, auto next_tile_t, auto mask_t) {
         constexpr int H = decltype(h_t)::value;
         constexpr bool NEXT_TILE = decltype(next_tile_t)::value, MASK = decltype(mask_t)::value;
@@ -249,12 +272,12 @@ static __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
         for (int qb = 0; qb < QB; qb++) {
             f32x16 acc;
             if (HAS_NEXT) {
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(use.k[0], qf[qb][0], negm[qb], 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(use.k[1], qf[qb][1], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(use.k[2], qf[qb][2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(use.k[0], qf[qb][0], negm[qb], 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(use.k[1], qf[qb][1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(use.k[2], qf[qb][2], acc, 0, 0, 0);
             }
             float pe[16], r4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-            bf16x8 pf[2];
+            f16x8 pf[2];
 #pragma unroll
             for (int g = 0; g < 16; g++) {
                 pe[g] = __builtin_amdgcn_exp2f(sc[qb][g]);
@@ -263,14 +286,14 @@ static __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
 #pragma unroll
             for (int s2 = 0; s2 < 2; s2++) {
 #pragma unroll
-                for (int j = 0; j < 8; j++) pf[s2][j] = (__bf16)pe[8 * s2 + j];
+                for (int j = 0; j < 8; j++) pf[s2][j] = (_Float16)pe[8 * s2 + j];
 #pragma unroll
-                for (int dt = 0; dt < 2; dt++) oacc[qb][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(use.v[s2][dt], pf[s2], oacc[qb][dt], 0, 0, 0);
+                for (int dt = 0; dt < 2; dt++) oacc[qb][dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(use.v[s2][dt], pf[s2], oacc[qb][dt], 0, 0, 0);
             }
             const float rs = (r4[0] + r4[1]) + (r4[2] + r4[3]);
             lrun[qb] += rs;
             rs_max = fmaxf(rs_max, rs);   // (v_max drops a NaN operand: an inf - inf cannot occur here, and rows of padding queries are never stored)
-            if (HAS_NEXT) sc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(use.k[3], qf[qb][3], acc, 0, 0, 0);
+            if (HAS_NEXT) sc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(use.k[3], qf[qb][3], acc, 0, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < QB * (HAS_NEXT ? 8 : 4); i++) {
@@ -291,7 +314,7 @@ static __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
         constexpr int H = decltype(h_t)::value;
         constexpr bool NEXT = decltype(next_tile_t)::value;
         ring_step(kt);
-        bf16x8 kf[4], vf[2][2], pf[2];
+        f16x8 kf[4], vf[2][2], pf[2];
         if (NEXT) qk_read(kf, kt + 1, H);
         const unsigned vb = stage_of(kt) + v_lane;
         v_read(vf[0], vb, H, 0);
@@ -299,9 +322,9 @@ static __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
         __builtin_amdgcn_sched_barrier(0);
         f32x16 acc;
         if (NEXT) {
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[0][0], negm[0], 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1], qf[0][1], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[2], qf[0][2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[0], qf[0][0], negm[0], 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[1], qf[0][1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[2], qf[0][2], acc, 0, 0, 0);
         }
         float pe[16], r4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
@@ -312,14 +335,14 @@ static __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
 #pragma unroll
         for (int s2 = 0; s2 < 2; s2++) {
 #pragma unroll
-            for (int j = 0; j < 8; j++) pf[s2][j] = (__bf16)pe[8 * s2 + j];
+            for (int j = 0; j < 8; j++) pf[s2][j] = (_Float16)pe[8 * s2 + j];
 #pragma unroll
-            for (int dt = 0; dt < 2; dt++) oacc[0][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[s2][dt], pf[s2], oacc[0][dt], 0, 0, 0);
+            for (int dt = 0; dt < 2; dt++) oacc[0][dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[s2][dt], pf[s2], oacc[0][dt], 0, 0, 0);
         }
         const float rs = (r4[0] + r4[1]) + (r4[2] + r4[3]);
         lrun[0] += rs;
         rs_max = fmaxf(rs_max, rs);
-        if (NEXT) sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[3], qf[0][3], acc, 0, 0, 0);
+        if (NEXT) sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[3], qf[0][3], acc, 0, 0, 0);
         // the first exp2 / adds / converts run while the fragments are on their way from LDS, then one MFMA : two exp2 : a few VALU
         __builtin_amdgcn_sched_group_barrier(0x400, 6, 0);
         __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
@@ -339,24 +362,27 @@ static __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
     if (PAIR) wait_landed(max(0, min(NST - 1, nkt - 1) - 2));
     else wait_landed(min(NST - 2, nkt - 1));
     __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int qb = 0; qb < QB; qb++) {   // the queries' offsets = 2 + their maxima over the sample keys (C = 0: negm is still zero)
+        f32x16 ss;
+        qk_mfma(ss, ksamp, qb);
+        const float m0 = row_max(ss) + A3_OFF_MARGIN;
+#pragma unroll
+        for (int g = 0; g < 16; g++) negm[qb][g] = -m0;
+    }
     {
-        bf16x8 kf0[4];
+        f16x8 kf0[4];
         if (BAL && role == 2) qk_read(kf0, 0, 1); else qk_read(kf0, 0, 0);
 #pragma unroll
-        for (int qb = 0; qb < QB; qb++) qk_mfma(sa[qb], kf0, qb);   // (C = 0: negm is still zero)
+        for (int qb = 0; qb < QB; qb++) {
+            qk_mfma(sa[qb], kf0, qb);   // = s - offset
+            mask_half(sa[qb], 0, h_first);   // (role 2 with at most 32 keys: nothing valid in its half -- its P are exp2(-1e30) = 0, its O and l stay 0)
+        }
     }
     if (!BAL || role == 0) {
         qk_read(fa.k, 0, 1);    // what half (0, 0) multiplies: K rows 32-63 and V keys 0-31 of tile 0
         v_read(fa.v[0], stage_of(0) + v_lane, 0, 0);
         v_read(fa.v[1], stage_of(0) + v_lane, 0, 1);
-    }
-#pragma unroll
-    for (int qb = 0; qb < QB; qb++) {   // the queries' offsets = their maxima over their first 32 keys (masked ones are -1e30)
-        mask_half(sa[qb], 0, h_first);
-        float m0 = row_max(sa[qb]);
-        if (m0 < -1e29f) m0 = 0.0f;   // (role 2 with at most 32 keys: nothing valid in its half -- its P are exp2(-1e30) = 0, its O and l stay 0)
-#pragma unroll
-        for (int g = 0; g < 16; g++) { negm[qb][g] = -m0; sa[qb][g] -= m0; }
     }
     A3_STAMP(-1);
     using T_ = std::true_type;
@@ -385,15 +411,15 @@ static __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
         for (int kt = 0; kt + 1 < nkt; kt++) half_only(sa[0], kt, H1{}, T_{});
         half_only(sa[0], nkt - 1, H1{}, F_{});
     }
-    // Did every probability stay in range?  A lane's row sum over its 16 keys of a half bounds each of them; 2^70 leaves 2^57 of fp32 headroom
-    // for the sums over 4096 keys.  (The flag lives in the first bytes of the ring -- 5 x 16 KiB is exactly half a CU's LDS, two workgroups
+    // Did every probability stay in range?  A lane's row sum over its 16 keys of a half bounds each of them: 2^15 keeps every P a finite fp16
+    // (the fp32 row sums are far from their own range).  (The flag lives in the first bytes of the ring -- 5 x 16 KiB is exactly half a CU's LDS, two workgroups
     // per CU -- hence the barriers: everybody done with the ring | flag cleared | flag set | flag read.)
     int* redo_flag = reinterpret_cast<int*>(smem);
     attn_wait_vmcnt<0>();
     __syncthreads();
     if (threadIdx.x == 0) *redo_flag = 0;
     __syncthreads();
-    if (__any(!(rs_max <= 0x1p70f)) && lane == 0) *redo_flag = 1;
+    if (__any(!(rs_max <= A3_P_LIMIT)) && lane == 0) *redo_flag = 1;
     __syncthreads();
     const bool redo = *redo_flag != 0;
     __syncthreads();
@@ -418,7 +444,7 @@ static __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
 #pragma unroll 1
             for (int h = 0; h < 2; h++) {
                 if (BAL && role == 2) break;   // (waves 6 / 7 only move tiles and keep the barriers; blocks 4 / 5 are redone whole by waves 4 / 5)
-                bf16x8 kf[4];
+                f16x8 kf[4];
                 qk_read(kf, gk, h);
 #pragma unroll
                 for (int qb = 0; qb < QB; qb++) {
@@ -441,12 +467,12 @@ static __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
                         for (int g = 0; g < 16; g++) oacc[qb][dt][g] *= alpha;
 #pragma unroll
                     for (int s2 = 0; s2 < 2; s2++) {
-                        bf16x8 pf, vf[2];
+                        f16x8 pf, vf[2];
 #pragma unroll
-                        for (int j = 0; j < 8; j++) pf[j] = (__bf16)sg[8 * s2 + j];
+                        for (int j = 0; j < 8; j++) pf[j] = (_Float16)sg[8 * s2 + j];
                         v_read(vf, vb, h, s2);
 #pragma unroll
-                        for (int dt = 0; dt < 2; dt++) oacc[qb][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[dt], pf, oacc[qb][dt], 0, 0, 0);
+                        for (int dt = 0; dt < 2; dt++) oacc[qb][dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[dt], pf, oacc[qb][dt], 0, 0, 0);
                     }
                 }
             }

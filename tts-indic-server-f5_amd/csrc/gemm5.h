@@ -276,7 +276,7 @@ F5_DEVICE void g5_generic_epilogue(const GemmArgs& p, const float* slab, int m0,
 }
 
 // Q / K rows of the fused QKV projection: bias, rotary embedding on head 0 (x-transformers interleaved pairs, applied before the head
-// split: F/model/modules.py:414-419), q / 8 (softmax scale, exact in bf16), bf16 row-major [M][2 D].  A 192-column tile can straddle
+// split: F/model/modules.py:414-419), q * log2(e) / 8 (softmax scale, base-2 exponents), fp16 row-major [M][2 D].  A 192-column tile can straddle
 // the Q | K or the K | V boundary: both are multiples of 64, so every 64-column panel is of one kind.
 template <int RB, int CB, int NST>
 F5_DEVICE void g5_qk_rows(const GemmArgs& p, const float* slab, int m0, int n0, int wave, int lane) {
@@ -315,19 +315,19 @@ F5_DEVICE void g5_qk_rows(const GemmArgs& p, const float* slab, int m0, int n0, 
                 const int which = n_base / D, nd = n_base - which * D + c4;
                 const f32x4 v = *reinterpret_cast<const f32x4*>(slab + rl * C::SLD + pn * 64 + c4) + bv[pn];
                 const float qs = which == 0 ? F5_Q_SCALE : 1.0f;
-                bf16x4 o;
+                float o[4];
                 if (rot && pn == rot_pn) {
                     // explicit product + fma: left to the compiler, the contraction of a*c - b*s differed between instantiations of the
-                    // round-1 epilogue -- a 1-ulp bf16 flip in a few q values that the 22-layer sampler amplifies to 5e-4
-                    o[0] = (__bf16)(__builtin_fmaf(v[0], c.x, -__fmul_rn(v[1], s2.x)) * qs);
-                    o[1] = (__bf16)(__builtin_fmaf(v[1], c.x, __fmul_rn(v[0], s2.x)) * qs);
-                    o[2] = (__bf16)(__builtin_fmaf(v[2], c.y, -__fmul_rn(v[3], s2.y)) * qs);
-                    o[3] = (__bf16)(__builtin_fmaf(v[3], c.y, __fmul_rn(v[2], s2.y)) * qs);
+                    // round-1 epilogue -- a 1-ulp flip in a few q values that the 22-layer sampler amplifies to 5e-4
+                    o[0] = __builtin_fmaf(v[0], c.x, -__fmul_rn(v[1], s2.x)) * qs;
+                    o[1] = __builtin_fmaf(v[1], c.x, __fmul_rn(v[0], s2.x)) * qs;
+                    o[2] = __builtin_fmaf(v[2], c.y, -__fmul_rn(v[3], s2.y)) * qs;
+                    o[3] = __builtin_fmaf(v[3], c.y, __fmul_rn(v[2], s2.y)) * qs;
                 } else {
 #pragma unroll
-                    for (int e = 0; e < 4; e++) o[e] = (__bf16)(v[e] * qs);
+                    for (int e = 0; e < 4; e++) o[e] = v[e] * qs;
                 }
-                if (rok) *reinterpret_cast<bf16x4*>(p.qk + (size_t)row * (2 * D) + which * D + nd) = o;
+                if (rok) store_f16x4(p.qk + (size_t)row * (2 * D) + which * D + nd, o);   // fp16, saturating (attention operands: common.h)
             }
         }
     };
@@ -341,7 +341,7 @@ F5_DEVICE void g5_qk_rows(const GemmArgs& p, const float* slab, int m0, int n0, 
     }
 }
 
-// V rows: slab[feature][token] (bias added by the writer) -> [D][ldvt] bf16: lane-linear (feature, 4 tokens) pairs, 8-byte stores,
+// V rows: slab[feature][token] (bias added by the writer) -> [D][ldvt] fp16: lane-linear (feature, 4 tokens) pairs, 8-byte stores,
 // 2 RB x 16-byte runs of tokens per feature row
 template <int RB, int CB, int NST>
 F5_DEVICE void g5_v_rows(const GemmArgs& p, const float* slab, int m0, int n0, int f_lo, int wave, int lane) {
@@ -353,10 +353,8 @@ F5_DEVICE void g5_v_rows(const GemmArgs& p, const float* slab, int m0, int n0, i
         const int f = f_lo + idx / T4, t4 = idx % T4;
         const int tok = m0 + t4 * 4;
         const f32x4 v = *reinterpret_cast<const f32x4*>(slab + f * C::SLDT + t4 * 4);
-        bf16x4 pk;
-#pragma unroll
-        for (int e = 0; e < 4; e++) pk[e] = (__bf16)v[e];
-        if (tok < p.M) *reinterpret_cast<bf16x4*>(p.vt + (size_t)(n0 + f - 2 * p.D) * p.ldvt + vt_col(tok)) = pk;
+        const float pk[4] = {v[0], v[1], v[2], v[3]};
+        if (tok < p.M) store_f16x4(p.vt + (size_t)(n0 + f - 2 * p.D) * p.ldvt + vt_col(tok), pk);
     }
 }
 

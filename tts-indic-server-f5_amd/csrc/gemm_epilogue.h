@@ -62,8 +62,8 @@ struct GemmArgs {
     const int* row_pos;      // [M_pad] frame index inside the row's sequence
     const float* rope_cos;   // [max_pos][32]
     const float* rope_sin;
-    __bf16* qk;              // [M_pad][2 D]
-    __bf16* vt;              // [D][ldvt]
+    __bf16* qk;              // [M_pad][2 D]  fp16 bits (attention operands are fp16: attn3.h)
+    __bf16* vt;              // [D][ldvt]     fp16 bits
     int ldvt;
     // fused LayerNorm behind the epilogue (gemm5 LNE kernels): ln.x == out_f32 (the residual stream this GEMM updates); ln_sync[slab] counts
     // the workgroups of a row slab that have stored their tile (monotonic: this launch waits for ln_target), *ln_err is set on a time-out
@@ -170,7 +170,7 @@ F5_DEVICE void epi_generic_rows(const GemmArgs& p, const float* stg, int m_base,
 }
 
 // Q / K blocks of the fused QKV projection: bias, rotary embedding on head 0 (x-transformers interleaved pairs, applied
-// before the head split: F/model/modules.py:414-419), q * 1/8 (softmax scale, exact in bf16), bf16 row-major [M][2 D]
+// before the head split: F/model/modules.py:414-419), q * log2(e) / 8 (softmax scale, base-2 exponents), fp16 row-major [M][2 D]
 template <int WN, int ROWS, bool ROT, bool GUARD, int SLD = WN>
 F5_DEVICE void epi_qk_rows_t(const GemmArgs& p, const float* stg, int m_base, int n_base, int lane) {
     constexpr int LPR = WN / 4, RPP = 64 / LPR, NQ = ROWS / RPP;
@@ -196,19 +196,19 @@ F5_DEVICE void epi_qk_rows_t(const GemmArgs& p, const float* stg, int m_base, in
 #pragma unroll
     for (int q = 0; q < NQ; q++) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(stg + (q * RPP + r0) * SLD + c4) + bv;
-        bf16x4 o;
+        float o[4];
         if (ROT) {
             // explicit product + fma: left to the compiler, the contraction of a*c - b*s differs between template instantiations (64- vs
-            // 128-wide wave tiles), a 1-ulp bf16 flip in a few q values that the 22-layer sampler amplifies to 5e-4 (tools/wide_pipeline_check.py)
-            o[0] = (__bf16)(__builtin_fmaf(v[0], cs[q].x, -__fmul_rn(v[1], sn[q].x)) * qs);
-            o[1] = (__bf16)(__builtin_fmaf(v[1], cs[q].x, __fmul_rn(v[0], sn[q].x)) * qs);
-            o[2] = (__bf16)(__builtin_fmaf(v[2], cs[q].y, -__fmul_rn(v[3], sn[q].y)) * qs);
-            o[3] = (__bf16)(__builtin_fmaf(v[3], cs[q].y, __fmul_rn(v[2], sn[q].y)) * qs);
+            // 128-wide wave tiles), a 1-ulp flip in a few q values that the 22-layer sampler amplifies to 5e-4 (tools/wide_pipeline_check.py)
+            o[0] = __builtin_fmaf(v[0], cs[q].x, -__fmul_rn(v[1], sn[q].x)) * qs;
+            o[1] = __builtin_fmaf(v[1], cs[q].x, __fmul_rn(v[0], sn[q].x)) * qs;
+            o[2] = __builtin_fmaf(v[2], cs[q].y, -__fmul_rn(v[3], sn[q].y)) * qs;
+            o[3] = __builtin_fmaf(v[3], cs[q].y, __fmul_rn(v[2], sn[q].y)) * qs;
         } else {
 #pragma unroll
-            for (int e = 0; e < 4; e++) o[e] = (__bf16)(v[e] * qs);
+            for (int e = 0; e < 4; e++) o[e] = v[e] * qs;
         }
-        if (!GUARD || m_base + q * RPP + r0 < p.M) *reinterpret_cast<bf16x4*>(op + (size_t)q * RPP * (2 * D)) = o;
+        if (!GUARD || m_base + q * RPP + r0 < p.M) store_f16x4(op + (size_t)q * RPP * (2 * D), o);   // fp16, saturating
     }
 }
 
@@ -259,10 +259,10 @@ F5_DEVICE void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[TM][TN], float* sl
                 const float bv = p.bias[n_wave + j * 32 + fr];
 #pragma unroll
                 for (int a4 = 0; a4 < 4; a4++) {
-                    bf16x4 pk;
+                    float pk[4];
 #pragma unroll
-                    for (int e = 0; e < 4; e++) pk[e] = (__bf16)(acc[i][j][a4 * 4 + e] + bv);
-                    *reinterpret_cast<bf16x4*>(p.vt + (size_t)nd * p.ldvt + vt_col(m_wave + i * 32 + 8 * a4 + 4 * fh)) = pk;
+                    for (int e = 0; e < 4; e++) pk[e] = acc[i][j][a4 * 4 + e] + bv;
+                    store_f16x4(p.vt + (size_t)nd * p.ldvt + vt_col(m_wave + i * 32 + 8 * a4 + 4 * fh), pk);
                 }
             }
         return;
@@ -325,10 +325,10 @@ F5_DEVICE void gemm_epilogue8_consumer(const GemmArgs& p, f32x16 (&acc)[2][TN], 
                 const float bv = p.bias[n_wave + j * 32 + fr];
 #pragma unroll
                 for (int a4 = 0; a4 < 4; a4++) {
-                    bf16x4 pk;
+                    float pk[4];
 #pragma unroll
-                    for (int e = 0; e < 4; e++) pk[e] = (__bf16)(acc[i][j][a4 * 4 + e] + bv);
-                    *reinterpret_cast<bf16x4*>(p.vt + (size_t)nd * p.ldvt + vt_col(m_wave + i * 32 + 8 * a4 + 4 * fh)) = pk;
+                    for (int e = 0; e < 4; e++) pk[e] = acc[i][j][a4 * 4 + e] + bv;
+                    store_f16x4(p.vt + (size_t)nd * p.ldvt + vt_col(m_wave + i * 32 + 8 * a4 + 4 * fh), pk);
                 }
             }
         return;                                        // (no barrier B for V blocks: the producers skip it too)

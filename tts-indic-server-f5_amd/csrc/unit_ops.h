@@ -208,9 +208,10 @@ __global__ __launch_bounds__(256) void op_pack_qkv_kernel(const float* q, const 
         const float qv = src >= 0 ? q[(size_t)src * D + c] * F5_Q_SCALE : 0.0f;   // q is pre-scaled by log2(e) / 8 like the QKV epilogue's
         const float kv = src >= 0 ? k[(size_t)src * D + c] : 0.0f;
         const float vv = src >= 0 ? v[(size_t)src * D + c] : 0.0f;
-        qk[(size_t)row * 2 * D + c] = (__bf16)qv;
-        qk[(size_t)row * 2 * D + D + c] = (__bf16)kv;
-        vt[(size_t)c * M_pad + vt_col(row)] = (__bf16)vv;
+        // fp16 bits, saturated, like the QKV epilogue's outputs
+        reinterpret_cast<_Float16*>(qk)[(size_t)row * 2 * D + c] = sat_f16(qv);
+        reinterpret_cast<_Float16*>(qk)[(size_t)row * 2 * D + D + c] = sat_f16(kv);
+        reinterpret_cast<_Float16*>(vt)[(size_t)c * M_pad + vt_col(row)] = sat_f16(vv);
     }
 }
 __global__ __launch_bounds__(256) void op_unpack_planes_kernel(const __bf16* hi, const __bf16* lo, int D, const int* frame_row, float* out) {
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(256) void op_unpack_planes_kernel(const __bf16* hi,
 }
 
 // softmax(q k^T / 8 + key-padding mask) v per (sequence, head), head dim 64 (F/model/modules.py:424-436): q / k / v fp32 [sum(seq_len)][64 heads]
-// are rounded to bf16 like the QKV epilogue's outputs (q after the 1/8 scale); out fp32 [sum(seq_len)][64 heads] = split-bf16 planes summed.
+// are rounded to fp16 like the QKV epilogue's outputs (q after the log2(e) / 8 scale); out fp32 [sum(seq_len)][64 heads] = split-bf16 planes summed.
 // impl 3 = attn3 (production), 4 = experiments/attn4.h (attn3 unless built with -DF5HIP_EXPERIMENTS).
 extern "C" int f5hip_op_attention(int32_t n_seq, const int32_t* seq_len, const int32_t* kv_len, int32_t heads, const float* q_dev,
                                   const float* k_dev, const float* v_dev, float* out_dev, int32_t impl, int32_t iters, double* avg_us, void* stream) {

@@ -40,13 +40,13 @@ def gemm(a, w, bias=None, *, prec=3, act="none", mul=None, res=None, row_keep=No
 
 
 def qkv(a, w, bias, row_pos, *, prec=3, iters=0):
-    """Fused QKV projection + epilogue.  Returns (q [M, D] (already scaled by log2(e) / 8), k [M, D], v [M, D]) as fp32 views of the bf16 outputs, avg_us."""
+    """Fused QKV projection + epilogue.  Returns (q [M, D] (already scaled by log2(e) / 8), k [M, D], v [M, D]) as fp32 views of the fp16 outputs, avg_us."""
     dev = a.device
     M, D = a.shape
     M_pad = (M + 127) // 128 * 128
     a, w, bias = (_f32(t, dev) for t in (a, w, bias))
-    qk = torch.zeros(M_pad, 2 * D, device=dev, dtype=torch.bfloat16)
-    vt = torch.zeros(D, M_pad, device=dev, dtype=torch.bfloat16)
+    qk = torch.zeros(M_pad, 2 * D, device=dev, dtype=torch.float16)
+    vt = torch.zeros(D, M_pad, device=dev, dtype=torch.float16)
     pos = np.ascontiguousarray(np.asarray(row_pos, dtype=np.int32))
     us = C.c_double(0.0)
     _lib.check(_lib.lib().f5hip_op_qkv(M, D, _p(a), _p(w), _p(bias), _p(pos), prec, _p(qk), _p(vt), iters, C.byref(us),

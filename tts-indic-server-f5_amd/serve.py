@@ -58,27 +58,44 @@ class MicroBatcher:
     request, keeps collecting for at most `max_wait_ms` or until `max_requests` are waiting, runs `run_batch(list_of_requests)` (one
     `infer.infer_requests` call = one library call over all chunks of all requests) and resolves the futures in order.  One batch is in
     flight at a time -- the library allows one call per handle -- and the next one forms while it runs, so under load the batch size
-    grows by itself.  A failing batch is retried request by request so one bad request cannot fail its neighbours."""
+    grows by itself.  A failing batch is retried request by request so one bad request cannot fail its neighbours -- unless the error
+    says the backend itself is gone (`no_retry`, e.g. a rank of a sharded job failed): then the whole batch fails at once.
+    `close()` resolves every request that is still queued with RuntimeError("MicroBatcher is closed"); nothing can be enqueued behind it."""
 
     def __init__(self, run_batch: Callable[[list], list], max_requests: int = 16, max_wait_ms: float = 5.0):
         self.run_batch, self.max_requests, self.max_wait = run_batch, int(max_requests), max_wait_ms / 1e3
         self._q: queue.Queue = queue.Queue()
-        self._stop = threading.Event()
+        self._closed = False
+        self._gate = threading.Lock()             # orders submit() against close(): no item can land behind the shutdown mark
         self.batch_sizes: list[int] = []          # observability: sizes of the batches run so far
         self._thread = threading.Thread(target=self._loop, name="f5hip-microbatcher", daemon=True)
         self._thread.start()
 
     def submit(self, request) -> Future:
-        if self._stop.is_set():
-            raise RuntimeError("MicroBatcher is closed")
         f: Future = Future()
-        self._q.put((request, f))
+        with self._gate:
+            if self._closed:
+                raise RuntimeError("MicroBatcher is closed")
+            self._q.put((request, f))
         return f
 
-    def close(self):
-        self._stop.set()
-        self._q.put(None)
-        self._thread.join(timeout=30)
+    def close(self, timeout: float = 30.0):
+        with self._gate:
+            if self._closed:
+                return
+            self._closed = True
+            self._q.put(None)                     # the shutdown mark: everything in front of it is still served
+        self._thread.join(timeout=timeout)
+        self._fail_pending()                      # (only non-empty if the worker thread did not get there: join timed out)
+
+    def _fail_pending(self):
+        while True:
+            try:
+                item = self._q.get_nowait()
+            except queue.Empty:
+                return
+            if item is not None:
+                item[1].set_exception(RuntimeError("MicroBatcher is closed"))
 
     def _collect(self):
         first = self._q.get()
@@ -92,15 +109,15 @@ class MicroBatcher:
             except queue.Empty:
                 break
             if item is None:
-                self._q.put(None)   # leave the shutdown mark for the loop
+                self._q.put(None)   # leave the shutdown mark for the loop (nothing can follow it: submit() is closed)
                 break
             batch.append(item)
         return batch
 
     def _loop(self):
-        while not self._stop.is_set():
+        while True:
             batch = self._collect()
-            if batch is None:
+            if batch is None:       # the shutdown mark: every request submitted before close() has been served
                 break
             self.batch_sizes.append(len(batch))
             try:
@@ -110,14 +127,16 @@ class MicroBatcher:
                 for (_, f), res in zip(batch, results):
                     f.set_result(res)
             except Exception as e:   # noqa: BLE001 -- isolate the failing request
-                if len(batch) == 1:
-                    batch[0][1].set_exception(e)
+                if len(batch) == 1 or getattr(e, "no_retry", False):
+                    for _, f in batch:
+                        f.set_exception(e)
                     continue
                 for r, f in batch:
                     try:
                         f.set_result(self.run_batch([r])[0])
                     except Exception as e1:   # noqa: BLE001
                         f.set_exception(e1)
+        self._fail_pending()
 
 
 class TTSManager:
@@ -136,6 +155,11 @@ class TTSManager:
         self.mel_spec_type = mel_spec_type
         self._prep_cache: dict = {}   # prompt path -> (PreparedVoice, ref_text): clip / trim / resample / mel run once per voice
         self._prep_lock = threading.Lock()   # route handlers run in a thread pool: concurrent first requests of a voice prepare it once
+        # The library allows ONE call in flight per handle (include/f5hip.h), the sampler keeps per-call state and noise comes from torch's
+        # global generator: every entry into the device path takes this lock.  Without a batcher, concurrent HTTP requests therefore run one
+        # after the other, like the reference's blocking `async def` handlers (S/routes/speech.py:19-41).
+        self._device_lock = threading.Lock()
+        self.request_timeout_s = 600.0       # a request never waits for its batch for ever
 
     def load(self, model_obj=None, vocoder=None):
         """Attach the sampler / vocoder objects (F5HipModel, F5HipVocos | F5HipBigVGAN), or build them with `loader`."""
@@ -151,8 +175,19 @@ class TTSManager:
         return self
 
     def _run_batch(self, requests):
-        res = infer.infer_requests(requests, self.model_obj, self.vocoder, mel_spec_type=self.mel_spec_type, **self.opts)
+        with self._device_lock:
+            res = infer.infer_requests(requests, self.model_obj, self.vocoder, mel_spec_type=self.mel_spec_type, **self.opts)
         return [np.asarray(w, dtype=np.float32) for w, _, _ in res]
+
+    def close(self):
+        """Unload: stop the batcher (requests already queued are served, later ones refused) and drop the model objects."""
+        if self.batcher is not None:
+            self.batcher.close()
+            self.batcher = None
+        closer = getattr(self.model_obj, "close", None)
+        if callable(closer):
+            closer()                             # ShardedSampler: releases the worker ranks
+        self.model = self.model_obj = self.vocoder = None
 
     def _voice(self, ref_audio_path, ref_text):
         """Once per voice: the reference's pre-step (clip to 15 s / trim silence, `preprocess_ref_audio_text`), then the prologue of
@@ -167,7 +202,7 @@ class TTSManager:
     def _call(self, text, ref_audio_path, ref_text):
         voice, ref_text_n = self._voice(ref_audio_path, ref_text)
         if self.batcher is not None:   # wait for the batch this request rides in (the route runs in a worker thread, see create_app)
-            return self.batcher.submit((voice, ref_text_n, text)).result()
+            return self.batcher.submit((voice, ref_text_n, text)).result(timeout=self.request_timeout_s)
         return self._run_batch([(voice, ref_text_n, text)])[0]
 
     def synthesize(self, text, ref_audio_path, ref_text):
@@ -256,6 +291,13 @@ def create_app(tts_manager: TTSManager, registry: VoiceRegistry):
 
 
 # ---------------------------------------------------------------------------------------------------------------- multi-GPU backend
+class ShardedJobError(RuntimeError):
+    """A rank of a sharded job failed.  Every rank still took part in the job's collectives (so nobody hangs), but the job has no
+    result and the batch must not be retried request by request on a backend in an unknown state: `no_retry` tells MicroBatcher so, the
+    sampler refuses further jobs, and the serving process should exit non-zero so that its supervisor starts fresh ranks."""
+    no_retry = True
+
+
 class ShardedSampler:
     """The model object of rank 0 in a one-process-per-GPU serving job: `sample_units` deals the units of a batch over the ranks
     (`sharding.shard_units`: longest-processing-time dealing with the SURVEY 8(d) cost model), every rank -- this one included --
@@ -263,6 +305,8 @@ class ShardedSampler:
     There is no collective inside the ODE loop: one job broadcast (tokens, frame counts, the reference mels of the voices in the
     batch: 188 KB per voice) and one gather per batch, RCCL over xGMI when the process group's backend is "nccl".
     Ranks > 0 run `rank_worker_loop(local_model)`; `close()` on rank 0 releases them.
+    Failure: a rank whose local `sample_units` raises still joins the gather with a failure header; rank 0 then raises
+    `ShardedJobError` after the collective has completed on every rank, and refuses later jobs (`failed`).
     Noise: every rank draws the noise of ITS units from its own generator (like the reference's per-call `torch.randn`, unseeded in
     `infer_batch_process`), so an unseeded result is not reproducible across world sizes; pass `seed=` in the knobs for that."""
 
@@ -272,12 +316,15 @@ class ShardedSampler:
         self.local, self.dist, self.torch = local_model, dist, torch
         self.device = device if device is not None else getattr(local_model, "device", torch.device("cpu"))
         self.vocab_char_map = getattr(local_model, "vocab_char_map", None)
+        self.failed: str | None = None
 
     # what infer.* needs from a model object
     def cond_mel(self, audio):
         return self.local.cond_mel(audio)
 
     def sample_units(self, audio, units, **knobs):
+        if self.failed:
+            raise ShardedJobError(f"sharded backend is down: {self.failed}")
         torch = self.torch
         b = len(units)
         audios = list(audio) if isinstance(audio, (list, tuple)) else [audio] * b
@@ -292,7 +339,11 @@ class ShardedSampler:
                 voice_of.append(len(voices) - 1)
         mels = [(self.local.cond_mel(a) if a.ndim == 2 else a)[0].to(torch.float32) for a in voices]
         job = dict(units=[(list(t), int(f)) for t, f in units], voice_of=voice_of, mel_shapes=[tuple(m.shape) for m in mels], knobs=knobs)
-        return _run_sharded_job(self.local, job, mels, self.device)
+        try:
+            return _run_sharded_job(self.local, job, mels, self.device)
+        except ShardedJobError as e:
+            self.failed = str(e)
+            raise
 
     def close(self):
         if self.dist.is_initialized() and self.dist.get_world_size() > 1:
@@ -300,7 +351,11 @@ class ShardedSampler:
 
 
 def _run_sharded_job(local_model, job, mels, device):
-    """Collective part shared by rank 0 (`job`, `mels` given) and the workers (both None): returns the mels of all units on rank 0."""
+    """Collective part shared by rank 0 (`job`, `mels` given) and the workers (both None): returns the mels of all units on rank 0.
+    Every rank that entered the job's broadcast also enters its gather, whatever its local sampler did."""
+    import sys
+    import traceback
+
     import torch
     import torch.distributed as dist
     from .sharding import gather_waves, shard_units
@@ -319,29 +374,42 @@ def _run_sharded_job(local_model, job, mels, device):
             mels.append(flat[k:k + a * b].view(a, b))
             k += a * b
     units = job["units"]
-    mine = shard_units([f for _, f in units], world)[rank]
-    outs = local_model.sample_units([mels[job["voice_of"][i]][None] for i in mine], [units[i] for i in mine], **job["knobs"]) if mine else []
-    # payload of a rank: the row count of each of its units, then their rows (a unit's final duration can exceed the planned frames:
-    # sample() raises it to lens + 1 like the reference, cfm.py:136)
-    mel_dim = mels[0].shape[1]
-    counts = torch.tensor([float(o.shape[0]) for o in outs], dtype=torch.float32, device=device)
-    packed = torch.cat([counts] + [o.reshape(-1).to(device, torch.float32) for o in outs])
+    shards = shard_units([f for _, f in units], world)
+    mine = shards[rank]
+    # payload of a rank: a status word (number of units, or -1: the local sampler failed), the row count of each unit, then their rows
+    # (a unit's final duration can exceed the planned frames: sample() raises it to lens + 1 like the reference, cfm.py:136)
+    local_error = None
+    try:
+        outs = local_model.sample_units([mels[job["voice_of"][i]][None] for i in mine], [units[i] for i in mine], **job["knobs"]) if mine else []
+        if len(outs) != len(mine):
+            raise RuntimeError(f"sample_units returned {len(outs)} mels for {len(mine)} units")
+        head = torch.tensor([float(len(outs))] + [float(o.shape[0]) for o in outs], dtype=torch.float32, device=device)
+        packed = torch.cat([head] + [o.reshape(-1).to(device, torch.float32) for o in outs])
+    except Exception as e:   # noqa: BLE001 -- reported through the collective, never by leaving it
+        local_error = e
+        traceback.print_exc(file=sys.stderr)
+        packed = torch.tensor([-1.0], dtype=torch.float32, device=device)
     got = gather_waves(packed, dst=0)
     if rank != 0:
         return []
+    bad = [r for r, flat_r in enumerate(got) if float(flat_r[0]) < 0]
+    if bad:
+        err = ShardedJobError(f"sample_units failed on rank(s) {bad} of {world}" + (f": {local_error!r}" if local_error is not None else ""))
+        raise err from local_error
+    mel_dim = mels[0].shape[1]
     result = [None] * len(units)
-    shards = shard_units([f for _, f in units], world)
     for r, flat_r in enumerate(got):
-        k = len(shards[r])
+        k = 1 + len(shards[r])
         for j, i in enumerate(shards[r]):
-            n = int(flat_r[j])
+            n = int(flat_r[1 + j])
             result[i] = flat_r[k:k + n * mel_dim].view(n, mel_dim)
             k += n * mel_dim
     return result
 
 
 def rank_worker_loop(local_model, device=None):
-    """What ranks > 0 of a serving job run: take part in every job rank 0's `ShardedSampler` broadcasts until it closes."""
+    """What ranks > 0 of a serving job run: take part in every job rank 0's `ShardedSampler` broadcasts until it closes.  A job whose
+    local sampler raised is reported to rank 0 inside the job's gather (`_run_sharded_job`) and the loop goes on."""
     import torch
     device = device if device is not None else getattr(local_model, "device", torch.device("cpu"))
     n = 0
