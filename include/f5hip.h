@@ -100,8 +100,9 @@ int f5hip_dit_set_ode_method(f5hip_dit* m, int32_t method);
 
 /* Attention kernel choice.  0 (default): the fastest form per launch shape -- a launch with 192-query tiles (e.g. one 10 s utterance) runs
  * the SIMD-balanced kernel, in which a third of the query blocks accumulate the two key halves of every tile separately and merge them at
- * the end: the same sums in a different association, so a sequence's output can differ in the last bits (~the bf16 rounding noise of P)
- * from what it gets inside a larger batch.  1: shape-invariant arithmetic -- every variant adds every query's terms in one order, so a
+ * the end: the same sums in a different fp32 association, so a sequence's output can differ in the last bits from what it gets inside a
+ * larger batch (the softmax offsets and the fp16 probabilities are the same in every variant).  In the mixed GEMM mode any last-bit
+ * difference grows to that mode's rounding-noise floor over a forward pass (profiles/r03_attn_mode_tapdiff.txt).  1: shape-invariant arithmetic -- every variant adds every query's terms in one order, so a
  * sequence's output does not depend on what it is batched with (bit-identical); ~3 % slower at batch 1.  Process-wide. */
 int f5hip_set_attention_shape_invariant(int32_t on);
 /* Per-kernel timing of the last f5hip_cfm_sample call when profiling was enabled with
@@ -110,7 +111,8 @@ int f5hip_set_attention_shape_invariant(int32_t on);
 int f5hip_set_profiling(int32_t enabled);
 int f5hip_get_profile(const char* kernel_class, double* total_ms, int64_t* launches);
 /* Launch counters of the GEMM dispatcher since the last reset (test instrumentation: proves which kernel a config exercised):
- * "gemm5_rb11" / "gemm5_rb8" (exact-fit tile heights 176 / 128), "gemm5_wide" (128- and 192-column tiles), "gemm3_wide";
+ * "gemm5_rb11" / "gemm5_rb8" (exact-fit tile heights 176 / 128), "gemm5_wide" (128- and 192-column tiles), "gemm3_wide",
+ * "gemm6" (256 x 256 ping-pong tiles: the batch-mode shapes);
  * name "reset" zeroes all of them (value may be NULL). */
 int f5hip_get_counter(const char* name, int64_t* value);
 

@@ -79,8 +79,8 @@ def base_model():
 
 
 def test_c3_share_batch8_copies_equal_single(base_model, attn_shape_invariant):
-    """8 identical utterances (M = 16 x 1408 rows: every block GEMM runs multi-round 176 x 128 / 176 x 192 tiles) give, item by item, the
-    batch-1 result (176 x 64 / 128 / 192 tiles in one round): only the tile shapes differ, the k order of every dot product does not.
+    """8 identical utterances (M = 16 x 1408 rows: every block GEMM runs gemm6's 256 x 256 tiles) give, item by item, the batch-1 result
+    (gemm5's 176 x 64 / 128 / 192 tiles in one round): only the kernel and its tile shapes differ, the k order of every dot product does not.
     (Shape-invariant attention arithmetic: see conftest.attn_shape_invariant; the default mode is compared in test_gpu_dit.)"""
     gc = torch.Generator().manual_seed(14)
     cond = torch.randn(1, 469, 100, generator=gc)
@@ -90,8 +90,8 @@ def test_c3_share_batch8_copies_equal_single(base_model, attn_shape_invariant):
     _reset_counters()
     eight, _ = base_model.sample(cond.expand(8, -1, -1), text.expand(8, -1), 1404, steps=2, cfg_strength=2.0, sway_sampling_coef=-1.0,
                                  y0=y0.expand(8, -1, -1))
-    # 2 steps x 22 layers x 4 block GEMMs, all on the exact-fit kernel; out / FF2 take 128-column tiles in batch mode (64 at batch 1)
-    assert _counter("gemm5_rb11") == 2 * 22 * 4 and _counter("gemm5_wide") == 2 * 22 * 4
+    # 2 steps x 22 layers x 4 block GEMMs, all on the batch-mode kernel (gemm6: 256 x 256 tiles; the single utterance ran gemm5's 176-row tiles)
+    assert _counter("gemm6") == 2 * 22 * 4 and _counter("gemm5_rb11") == 0
     for i in range(8):
         assert _report(f"C3 share item {i}", eight[i], one[0]) < 2e-5
 

@@ -73,7 +73,12 @@ CASES = [
     (1536, 768, 768, 3, "none", True, True, True, False, False, "gemm5_rb8"),         # F5-Small widths (C1): 128-row tiles
     (2816, 100, 1024, 3, "none", True, False, False, False, False, None),              # N = mel_dim: partial column panel
     (2816, 1024, 128, 3, "silu", True, False, False, False, False, None),              # K shorter than the ring depth
-    (22528, 1024, 1024, 3, "none", True, True, True, False, False, "gemm5_wide"),      # C3 share: 8 utterances x 2 branches (batch mode, 8 rounds)
+    (22528, 1024, 1024, 3, "none", True, True, True, False, False, "gemm6"),           # C3 share: 8 utterances x 2 branches (batch mode: 256 x 256 ping-pong tiles)
+    (22528, 2048, 1024, 3, "gelu_tanh", True, False, False, False, True, "gemm6"),      # FF1 at the C3 share: fp16 plane out
+    (22528, 1024, 2048, 3, "none", True, True, True, False, False, "gemm6"),           # FF2 at the C3 share (32 K-tiles)
+    (22400, 1024, 1024, 3, "none", True, True, True, True, False, "gemm6"),            # ragged batch: the last 256-row tile has 128 valid rows; masked rows
+    (16384, 1024, 64, 3, "silu", True, False, False, False, False, "gemm6"),           # one K-tile only (prologue without a second tile)
+    (16384, 1024, 128, 3, "none", True, False, True, False, False, "gemm6"),           # two K-tiles
     (2816, 1024, 1024, 2, "none", True, True, True, False, False, None),               # bf16x3 (strict mode)
     (2816, 2048, 1024, 1, "gelu_tanh", True, False, False, False, False, None),        # plain bf16
     (200, 512, 1024, 2, "gelu_erf", True, False, False, False, False, None),           # Vocos-sized, erf GELU
@@ -133,7 +138,7 @@ def test_gemm_f16_output_saturates():
     assert (out[~ok].float().cpu().abs()[big] == 65504.0).all()
 
 
-@pytest.mark.parametrize("M,D,prec", [(2816, 1024, 3), (1404, 1024, 3), (1536, 768, 3), (2816, 1024, 2), (300, 256, 2)])
+@pytest.mark.parametrize("M,D,prec", [(2816, 1024, 3), (1404, 1024, 3), (1536, 768, 3), (2816, 1024, 2), (300, 256, 2), (22528, 1024, 3), (8320, 768, 3)])
 def test_qkv_unit_op(M, D, prec):
     """Fused QKV projection + epilogue against a reference that applies x-transformers' interleaved rotary embedding to channels
     0..63 of q and k (head 0 only: F/model/modules.py:414-426), scales q by log2(e) / 8 (the attention kernel works in base-2 exponents) and rounds to fp16 like the kernel's outputs."""
@@ -154,6 +159,8 @@ def test_qkv_unit_op(M, D, prec):
     gq, gk, gv, _ = ops.qkv(a.to(DEV), w.to(DEV), bias, pos.numpy(), prec=prec)
     if prec == 3 and M == 2816:
         assert _counter("gemm5_wide") == 1 and _counter("gemm5_rb11") == 1
+    if M >= 8320:
+        assert _counter("gemm6") == 1          # batch-mode shapes: the 256 x 256 ping-pong kernel (all-Q, all-K and all-V tiles; 8320 = 32.5 row tiles)
     for name, got, ref in (("q", gq, q), ("k", gk, k), ("v", gv, v)):
         err = (got.cpu() - ref.half().float()).abs()
         # fp16 outputs: identical up to accumulation-order flips of the last fp16 bit on some elements

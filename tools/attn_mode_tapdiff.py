@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Per-layer account of "the same utterance, another attention kernel variant" (VERDICT r2 item 1c).  GPU.
 
-One F5-Base forward at the C2 geometry (N = 1404), hidden state behind n blocks, three runs per GEMM mode:
+One F5-Base forward over TWO copies of the C2 utterance (N = 1404 each: the 2 x 16 x 8 = 256-workgroup launch of a CFG pair, which is what
+selects the balanced kernel), hidden state behind n blocks, three runs per GEMM mode:
   A  default attention (balanced 8-wave kernel: the key halves of a third of the query blocks are summed separately)
   B  f5hip_set_attention_shape_invariant(1) (6-wave kernel, one association for every query block)
   C  like B, but the INPUT x perturbed by 1 ulp-sized relative noise (2^-24): no attention difference at all
@@ -25,9 +26,9 @@ def rms(a, b):
 def main():
     sd = synth.dit_state_dict()
     g = torch.Generator().manual_seed(14)
-    cond = torch.randn(1, 1404, 100, generator=g) * (torch.arange(1404)[None, :, None] < 469)
-    text = synth.text_ids()
-    x = synth.noise(1404, 0)[None]
+    cond = (torch.randn(1, 1404, 100, generator=g) * (torch.arange(1404)[None, :, None] < 469)).expand(2, -1, -1).contiguous()
+    text = synth.text_ids().expand(2, -1).contiguous()
+    x = synth.noise(1404, 0)[None].expand(2, -1, -1).contiguous()
     x_eps = x * (1.0 + 2.0 ** -24 * torch.randn(x.shape, generator=g))
     inv = lambda on: _lib.check(_lib.lib().f5hip_set_attention_shape_invariant(int(on)), "set_attention_shape_invariant")
     for planes, name in ((2, "bf16x3 (split bf16 everywhere)"), (3, "mixed (fp16 block GEMMs)")):

@@ -163,6 +163,21 @@ F5_DEVICE void g5_write_slab(f32x4 (&acc)[MRB][MCB], float* slab, int rb0, int n
     }
 }
 
+// The arithmetic of the generic epilogue on 4 consecutive features of one row, shared by every epilogue form of gemm5 / gemm6 (slab row
+// phase, direct-from-accumulator): one function, explicit fma, so that which kernel computed a row cannot change its bits.
+template <int ACT, bool RES>
+F5_DEVICE f32x4 g5_epi_value(f32x4 acc, f32x4 bias, f32x4 mul, f32x4 res, bool zero_row) {
+    f32x4 v = acc + bias;
+    if (ACT != ACT_NONE) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) v[e] = apply_act(v[e], ACT);
+    }
+    if (zero_row) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; e++) v[e] = RES ? __builtin_fmaf(v[e], mul[e], res[e]) : __fmul_rn(v[e], mul[e]);
+    return v;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------------
 // generic row phase: v = act(acc + bias); rows with row_keep == 0 -> 0; v = v * mul + res; fp32 and / or 16-bit outputs.
 // Work unit = one group of 4 rows x the tile's NPAN panels of 64 columns (lane -> row lane >> 4, columns 4 (lane & 15) .. + 3 of each
@@ -206,14 +221,7 @@ F5_DEVICE void g5_generic_tail(const GemmArgs& p, const float* slab, int m0, int
 #pragma unroll
         for (int pn = 0; pn < NPAN; pn++) {
             const int n = n0 + pn * 64 + c4;
-            f32x4 v = *reinterpret_cast<const f32x4*>(slab + rl * C::SLD + pn * 64 + c4) + bv[pn];
-            if (ACT != ACT_NONE) {
-#pragma unroll
-                for (int e = 0; e < 4; e++) v[e] = apply_act(v[e], ACT);
-            }
-            if (GUARD && !keep) v = (f32x4){0.f, 0.f, 0.f, 0.f};
-            v = v * mv[pn];
-            if (RES) v = v + rs[pn];
+            const f32x4 v = g5_epi_value<ACT, RES>(*reinterpret_cast<const f32x4*>(slab + rl * C::SLD + pn * 64 + c4), bv[pn], mv[pn], rs[RES ? pn : 0], GUARD && !keep);
             if (!GUARD || (nok[pn] && row < p.M)) {
                 if (OUTF) *reinterpret_cast<f32x4*>(p.out_f32 + (size_t)row * p.ldo + n) = v;
                 const float vv[4] = {v[0], v[1], v[2], v[3]};

@@ -13,6 +13,8 @@ hipError_t f5_launch_gemm3(int prec, int epi, int bn, const GemmArgs& a, int m_p
 // gemm5.h: exact-fit (16 rb) x (16 cb) tiles, 64-deep k-steps, fp16 operands
 hipError_t f5_launch_gemm5_generic(const GemmArgs& a, int rb, int cb, int n_pad, hipStream_t st);
 hipError_t f5_launch_gemm5_qkv(const GemmArgs& a, int rb, int cb, int n_pad, hipStream_t st);
+// gemm6.h: 256 x 256 x 64 ping-pong tiles, fp16 operands: the batch-mode shapes (hipErrorInvalidValue: n_pad % 256, K % 64, D % 256)
+hipError_t f5_launch_gemm6(int epi, const GemmArgs& a, int n_pad, hipStream_t st);
 // a residual GEMM (64-column tiles of a 1024-wide stream) with the LayerNorm that follows it fused behind the epilogue (GemmArgs::ln ...):
 // one resident wave of workgroups, 16 column tiles per row slab; hipErrorInvalidValue otherwise.  Experiments builds only (measured
 // slower than the two launches it replaces).

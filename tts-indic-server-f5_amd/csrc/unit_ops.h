@@ -58,6 +58,42 @@ static int gemm5_stamp_report(OpBufs& b, int M, int N, int K, hipStream_t st, La
     return 0;
 }
 
+// diagnostics of gemm6 (F5HIP_GEMM6_STAMPS=1, tools/gemm6_stamps.py): per-workgroup time line from the kernel's run-time stamps
+template <typename Launch>
+static int gemm6_stamp_report(OpBufs& b, int M, int N, int K, hipStream_t st, Launch launch) {
+    const int maxg = 4096;
+    unsigned long long* d = b.get<unsigned long long>((size_t)maxg * 16);
+    if (!d) return 0;
+    (void)hipMemsetAsync(d, 0, sizeof(unsigned long long) * maxg * 16, st);
+    for (int rep = 0; rep < 3; rep++) CK(launch(d, rep));
+    (void)hipStreamSynchronize(st);
+    std::vector<unsigned long long> h((size_t)maxg * 16);
+    (void)hipMemcpy(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost);
+    unsigned long long tmin = ~0ull, tmax = 0;
+    int ng = 0;
+    for (int g2 = 0; g2 < maxg; g2++) if (h[(size_t)g2 * 16]) { ng = g2 + 1; tmin = std::min(tmin, h[(size_t)g2 * 16]); tmax = std::max(tmax, std::max(h[(size_t)g2 * 16 + 6], h[(size_t)g2 * 16 + 14])); }
+    fprintf(stderr, "[gemm6 stamps] M %d N %d K %d: %d workgroups, first start -> last end %.2f us\n", M, N, K, ng, (tmax - tmin) * 0.01);
+    const char* names[6] = {"k-loop", "quarter 0", "quarter 1", "quarter 2", "quarter 3", "store drain"};
+    for (int w = 0; w < 2; w++)
+        for (int i = 0; i < 6; i++) {
+            std::vector<double> v;
+            for (int g2 = 0; g2 < ng; g2++) {
+                const unsigned long long t0 = h[(size_t)g2 * 16 + w * 8 + i], t1 = h[(size_t)g2 * 16 + w * 8 + i + 1];
+                if (t0 && t1) v.push_back((t1 - t0) * 0.01);
+            }
+            if (v.empty()) continue;
+            std::sort(v.begin(), v.end());
+            fprintf(stderr, "[gemm6 stamps]   wave %d  %-12s duration min %6.2f  median %6.2f  max %6.2f us\n", w * 4, names[i], v.front(), v[v.size() / 2], v.back());
+        }
+    {   // start times: how the rounds lay out
+        std::vector<double> v;
+        for (int g2 = 0; g2 < ng; g2++) v.push_back((h[(size_t)g2 * 16] - tmin) * 0.01);
+        std::sort(v.begin(), v.end());
+        fprintf(stderr, "[gemm6 stamps]   workgroup start: 25 %% %.2f  50 %% %.2f  75 %% %.2f  90 %% %.2f  last %.2f us\n", v[ng / 4], v[ng / 2], v[3 * ng / 4], v[9 * ng / 10], v.back());
+    }
+    return 0;
+}
+
 extern "C" int f5hip_op_gemm(int32_t M, int32_t N, int32_t K, const float* a_dev, const float* w_dev, const float* bias_dev, int32_t prec,
                              int32_t act, const float* mul_dev, const float* res_dev, const uint8_t* row_keep_host, float* out_dev,
                              uint16_t* out16_dev, int32_t w_copies, int32_t iters, double* avg_us, void* stream) {
@@ -104,6 +140,12 @@ extern "C" int f5hip_op_gemm(int32_t M, int32_t N, int32_t K, const float* a_dev
     }
     if (getenv("F5HIP_GEMM5_STAMPS"))
         CK(gemm5_stamp_report(b, M, N, K, st, [&](unsigned long long* d, int rep) {
+            GemmArgs g = args_for(Ws[rep % w_copies]);
+            g.stamps = d;
+            return run_gemm_n(prec, M_pad, g, Ws[rep % w_copies], EPI_GENERIC, false, 128, st);
+        }));
+    if (getenv("F5HIP_GEMM6_STAMPS"))
+        CK(gemm6_stamp_report(b, M, N, K, st, [&](unsigned long long* d, int rep) {
             GemmArgs g = args_for(Ws[rep % w_copies]);
             g.stamps = d;
             return run_gemm_n(prec, M_pad, g, Ws[rep % w_copies], EPI_GENERIC, false, 128, st);

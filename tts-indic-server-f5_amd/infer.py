@@ -22,6 +22,7 @@ import numpy as np
 import torch
 
 from .audio_prep import preprocess_ref_audio_text, remove_silence_edges  # noqa: F401  (F/infer/utils_infer.py:263-350)
+from .loaders import DiT, MMDiT, UNetT, load_checkpoint, load_model, load_vocoder  # noqa: F401  (F/infer/utils_infer.py:92-130,175-260)
 
 # ----------------------------------------- F/infer/utils_infer.py:40-53
 target_sample_rate = 24000
