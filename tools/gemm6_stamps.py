@@ -11,6 +11,7 @@ import torch  # noqa: E402
 from tts_indic_server_f5_amd import ops  # noqa: E402
 
 M = int(os.environ.get("M", 22528))
+print("F5HIP_GEMM6 =", os.environ.get("F5HIP_GEMM6", "(auto)"), flush=True)
 for name, N, K, act, out16, res in (("out", 1024, 1024, "none", False, True), ("FF1", 2048, 1024, "gelu_tanh", True, False), ("FF2", 1024, 2048, "none", False, True),
                                     ("out, K = 64 (epilogue only)", 1024, 64, "none", False, True), ("FF1, K = 64 (epilogue only)", 2048, 64, "gelu_tanh", True, False)):
     g = torch.Generator().manual_seed(1)

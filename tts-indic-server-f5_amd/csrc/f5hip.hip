@@ -512,7 +512,7 @@ static GemmArgs gemm_base(const Plane2& A, int lda, const PackedW& W, int M) {
 
 static int g_gemm_impl = -1;   // F5HIP_GEMM_IMPL: 0 = automatic; 1 = register-staged kernel only (gemm.h); 3 = gemm3 instead of gemm5 (A/B); 2 / 4 = experiments build only
 static long long g_counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // f5hip_get_counter: gemm5 launches with RB 11 / RB 8 / 1 x 4 consumer layout / gemm3 wide-tile launches / ... / gemm6 launches
-static int g_gemm6_mode = -1;   // F5HIP_GEMM6: 0 = never, 1 = whenever the shape is legal, unset = automatic (batch-mode shapes)
+static int g_gemm6_mode = -1;   // F5HIP_GEMM6: 0 = never, 1 = whenever the shape is legal, 256 / 176 = that tile height whenever legal, unset = automatic (batch-mode shapes)
 
 // Kernel choice per GEMM (measured: profiles/r02_fillrate_microbench.txt, profiles/r01_gemm_microbench.txt, tools/gemm_microbench.py):
 //   fp16 one-plane operands with K % 64 == 0 (the four transformer-block GEMMs of the DiT in mixed mode): gemm5, exact-fit tiles;
@@ -555,10 +555,11 @@ static int run_gemm_n(int nsplit, int mp, GemmArgs& a, const PackedW& W, int epi
             g_gemm6_mode = env6 ? atoi(env6) : 2;
         }
         // gemm6 (256 x 256 ping-pong tiles): the batch-mode shapes -- enough tiles to occupy the chip in their first round
-        const long long tiles256 = (long long)((a.M + 255) / 256) * (np / 256);
         const bool legal6 = g_gemm_impl == 0 && a.K % 64 == 0 && np % 256 == 0 && (epi != EPI_QKV || a.D % 256 == 0);
-        if (legal6 && (g_gemm6_mode == 1 || (g_gemm6_mode == 2 && tiles256 >= 224))) {
-            e = f5_launch_gemm6(epi, a, np, st);
+        int rows6 = legal6 ? gemm6_choose_rows(a.M, np) : 0;
+        if (legal6 && (g_gemm6_mode == 1 || g_gemm6_mode == 256 || g_gemm6_mode == 176)) rows6 = g_gemm6_mode == 1 ? (rows6 ? rows6 : 256) : g_gemm6_mode;   // (forced: tools)
+        if (rows6 && g_gemm6_mode != 0) {
+            e = f5_launch_gemm6(epi, rows6, a, np, st);
             g_counters[7]++;
         } else if ((g_gemm_impl == 0 || g_gemm_impl == 5) && a.K % 64 == 0 && c5.rb) {
             e = epi == EPI_QKV ? f5_launch_gemm5_qkv(a, c5.rb, c5.cb, np, st) : f5_launch_gemm5_generic(a, c5.rb, c5.cb, np, st);

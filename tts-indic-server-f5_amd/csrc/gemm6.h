@@ -35,27 +35,41 @@
 #include "attn_common.h"
 #include "gemm5.h"
 
+// RBW = 16-row blocks per wave: 8 -> 256-row tiles; 6 -> tiles of 176 rows in a 192-row LDS image (the last row block of the second wave
+// group multiplies the first 16 rows of the NEXT tile -- real, finite data -- and is never stored): 176 divides the row counts of this
+// path (M_pad = 1408 per sequence: 22 528 = 128 x 176), so out / FF2 / QKV at the C3 share are 2 / 2 / 6 FULL rounds on the 256 CUs instead
+// of 1.375 / 1.375 / 4.125 rounds of 256-row tiles that cost 2 / 2 / 5.
+template <int RBW>
 struct Gemm6Cfg {
-    static constexpr int BM = 256, BN = 256, HT = 16384, BUF = 4 * HT, LDS = 2 * BUF;
-    using Q = Gemm5Cfg<4, 16, 3>;   // the geometry of one 64-row quarter of the tile as the gemm5 epilogue functions see it (slab strides)
+    static_assert(RBW == 8 || RBW == 6, "8 = 256-row tiles, 6 = 176-row tiles");
+    static constexpr int QR = RBW / 2;                      // row blocks per quadrant
+    static constexpr int BM = RBW == 8 ? 256 : 176;         // rows a tile owns (its stride)
+    static constexpr int BN = 256;
+    static constexpr int AH = RBW * 2048, WH = 16384;       // half-tile bytes: RBW * 16 rows (A), 128 rows (W), 128-byte rows
+    static constexpr int APIECES = RBW * 2;                 // 1 KiB pieces of an A half-tile
+    static constexpr int BUF = 2 * AH + 2 * WH, LDS = 2 * BUF;
+    using Q = Gemm5Cfg<QR, 16, 3>;   // the geometry of one quarter (QR row blocks) of the tile as the gemm5 epilogue functions see it (slab strides)
     static_assert(Q::SLAB <= LDS && Q::SLAB_T <= LDS, "the quarter-tile slabs alias the dead ring");
 };
 
 // one K-loop; SWAP as in gemm5 (true: the W fragment is the MFMA's A operand, a lane holds 4 consecutive FEATURES of a token)
-template <bool F16, bool SWAP>
-F5_DEVICE void g6_kloop(const GemmArgs& p, char* smem, int m0, int n0, int n_rows_w, int wave, int lane, f32x4 (&acc)[8][4]) {
-    constexpr int HT = Gemm6Cfg::HT, BUF = Gemm6Cfg::BUF;
+template <bool F16, bool SWAP, int RBW>
+F5_DEVICE void g6_kloop(const GemmArgs& p, char* smem, int m0, int n0, int n_rows_w, int wave, int lane, f32x4 (&acc)[RBW][4]) {
+    using C = Gemm6Cfg<RBW>;
+    constexpr int AH = C::AH, WH = C::WH, BUF = C::BUF, QR = C::QR;
     const int wr = wave >> 2, wc = wave & 3;
     const int nk = p.K >> 6;
     const int fr = lane & 15, fq = lane >> 4;
     const int off0 = fr * 128 + ((fq ^ (fr >> 1)) << 4);
 #pragma unroll
-    for (int i = 0; i < 8; i++)
+    for (int i = 0; i < RBW; i++)
 #pragma unroll
         for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // DMA sources: half-tile h (0 A-lo, 1 A-hi, 2 W-lo, 3 W-hi), piece pp (0 / 1) = rows (wave + 8 pp) * 8 + (lane >> 3) of the half-tile.
     // Rows past the matrices (a partial last slab) re-read the last valid row: finite data, never stored.
+    // An A half-tile has C::APIECES pieces (16 or 12): every wave moves piece `wave`, and piece `wave + 8` if there is one.
+    const bool a_second = wave + 8 < C::APIECES;   // (wave-uniform)
     const char* src[4][2];
 #pragma unroll
     for (int h = 0; h < 4; h++)
@@ -64,25 +78,25 @@ F5_DEVICE void g6_kloop(const GemmArgs& p, char* smem, int m0, int n0, int n_row
             const int row = (wave + 8 * pp) * 8 + (lane >> 3);
             const int chunk = (lane & 7) ^ ((row >> 1) & 7);
             const bool isA = h < 2;
-            const int grow = isA ? min(m0 + (h & 1) * 128 + row, p.M - 1) : min(n0 + (h & 1) * 128 + row, n_rows_w - 1);
+            const int grow = isA ? min(m0 + (h & 1) * (RBW * 16) + row, p.M - 1) : min(n0 + (h & 1) * 128 + row, n_rows_w - 1);
             const __bf16* base = isA ? p.A[0] + (size_t)grow * p.lda : p.W[0] + (size_t)grow * p.ldw;
             src[h][pp] = reinterpret_cast<const char*>(base + chunk * 8);
         }
     auto stage = [&](int h, int kt) {   // half-tile h of K-tile kt -> buffer kt & 1
-        char* dst = smem + (kt & 1) * BUF + h * HT + wave * 1024;
+        char* dst = smem + (kt & 1) * BUF + (h < 2 ? h * AH : 2 * AH + (h - 2) * WH) + wave * 1024;
         attn_lds_dma16(src[h][0] + (size_t)kt * 128, dst);
-        attn_lds_dma16(src[h][1] + (size_t)kt * 128, dst + 8192);
+        if (h >= 2 || a_second) attn_lds_dma16(src[h][1] + (size_t)kt * 128, dst + 8192);
     };
-    bf16x8 fa[8], fb[2][4];   // fa[kh * 4 + i]: row block i of the current row half; fb[qn][kh * 2 + j]
+    bf16x8 fa[2 * QR], fb[2][4];   // fa[kh * QR + i]: row block i of the current row half; fb[qn][kh * 2 + j]
     auto read_a = [&](int kt, int qm) {
-        const char* b = smem + (kt & 1) * BUF + wr * HT + qm * 8192;
+        const char* b = smem + (kt & 1) * BUF + wr * AH + qm * (QR * 2048);
 #pragma unroll
         for (int kh = 0; kh < 2; kh++)
 #pragma unroll
-            for (int i = 0; i < 4; i++) fa[kh * 4 + i] = *reinterpret_cast<const bf16x8*>(b + i * 2048 + (off0 ^ (kh << 6)));
+            for (int i = 0; i < QR; i++) fa[kh * QR + i] = *reinterpret_cast<const bf16x8*>(b + i * 2048 + (off0 ^ (kh << 6)));
     };
     auto read_b = [&](int kt, int qn) {
-        const char* b = smem + (kt & 1) * BUF + (2 + (wc >> 1)) * HT + (wc & 1) * 8192 + qn * 4096;
+        const char* b = smem + (kt & 1) * BUF + 2 * AH + (wc >> 1) * WH + (wc & 1) * 8192 + qn * 4096;
 #pragma unroll
         for (int kh = 0; kh < 2; kh++)
 #pragma unroll
@@ -99,11 +113,11 @@ F5_DEVICE void g6_kloop(const GemmArgs& p, char* smem, int m0, int n0, int n_row
 #pragma unroll
         for (int kh = 0; kh < 2; kh++)
 #pragma unroll
-            for (int i = 0; i < 4; i++)
+            for (int i = 0; i < QR; i++)
 #pragma unroll
                 for (int j = 0; j < 2; j++)
-                    acc[QM * 4 + i][QN * 2 + j] = SWAP ? mfma_16x16x32<F16>(fb[QN][kh * 2 + j], fa[kh * 4 + i], acc[QM * 4 + i][QN * 2 + j])
-                                                       : mfma_16x16x32<F16>(fa[kh * 4 + i], fb[QN][kh * 2 + j], acc[QM * 4 + i][QN * 2 + j]);
+                    acc[QM * QR + i][QN * 2 + j] = SWAP ? mfma_16x16x32<F16>(fb[QN][kh * 2 + j], fa[kh * QR + i], acc[QM * QR + i][QN * 2 + j])
+                                                        : mfma_16x16x32<F16>(fa[kh * QR + i], fb[QN][kh * 2 + j], acc[QM * QR + i][QN * 2 + j]);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
@@ -153,8 +167,9 @@ F5_DEVICE void g6_kloop(const GemmArgs& p, char* smem, int m0, int n0, int n_row
 // segments, the next row block's in flight while the current one is finished).  The per-element arithmetic is g5_epi_value, gemm5's.
 // (Through the slab, four quarters of [write | barrier | row phase | barrier], the epilogue took 13-17 us of a 39-43 us tile:
 // profiles/r03_gemm6_stamps_slab_epilogue.txt.)
-template <int ACT, bool RES, bool OUTF, int OUTS, bool GUARD>
-F5_DEVICE void g6_direct_tail(const GemmArgs& p, f32x4 (&acc)[8][4], int m_w, int n_w, int lane) {
+// n_blk = row blocks of this wave that belong to the tile (RBW, or one fewer for the second group of a 176-row tile)
+template <int ACT, bool RES, bool OUTF, int OUTS, bool GUARD, int RBW>
+F5_DEVICE void g6_direct_tail(const GemmArgs& p, f32x4 (&acc)[RBW][4], int m_w, int n_w, int n_blk, int lane) {
     const int fr = lane & 15, fq = lane >> 4;
     f32x4 bv[4], mv[4];
     bool nok[4];
@@ -174,12 +189,13 @@ F5_DEVICE void g6_direct_tail(const GemmArgs& p, f32x4 (&acc)[8][4], int m_w, in
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             dst[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (i < 8 && (!GUARD || (nok[j] && row < p.M))) dst[j] = *reinterpret_cast<const f32x4*>(p.res + (size_t)row * p.ldres + n_w + j * 16 + fq * 4);
+            if (i < n_blk && (!GUARD || (nok[j] && row < p.M))) dst[j] = *reinterpret_cast<const f32x4*>(p.res + (size_t)row * p.ldres + n_w + j * 16 + fq * 4);
         }
     };
     load_res(0, rs);
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
+    for (int i = 0; i < RBW; i++) {
+        if (i >= n_blk) break;                                 // (wave-uniform)
         load_res(i + 1, rn);
         const int row = m_w + i * 16 + fr;
         int keep = 1;
@@ -208,35 +224,36 @@ F5_DEVICE void g6_direct_tail(const GemmArgs& p, f32x4 (&acc)[8][4], int m_w, in
     }
 }
 
-template <int ACT, bool GUARD>
-F5_DEVICE void g6_direct_variants(const GemmArgs& p, f32x4 (&acc)[8][4], int m_w, int n_w, int lane) {
+template <int ACT, bool GUARD, int RBW>
+F5_DEVICE void g6_direct_variants(const GemmArgs& p, f32x4 (&acc)[RBW][4], int m_w, int n_w, int n_blk, int lane) {
     const bool res = p.res != nullptr, outf = p.out_f32 != nullptr, outs = p.out_hi != nullptr;
     // the (residual, fp32 out, 16-bit out) combinations in use on the path: the table of g5_generic_variants
     if (ACT == ACT_NONE) {
         if (res) {
-            if (outf && outs) g6_direct_tail<ACT, true, true, 1, GUARD>(p, acc, m_w, n_w, lane);
-            else if (outf) g6_direct_tail<ACT, true, true, 0, GUARD>(p, acc, m_w, n_w, lane);
-            else g6_direct_tail<ACT, true, false, 1, GUARD>(p, acc, m_w, n_w, lane);
+            if (outf && outs) g6_direct_tail<ACT, true, true, 1, GUARD, RBW>(p, acc, m_w, n_w, n_blk, lane);
+            else if (outf) g6_direct_tail<ACT, true, true, 0, GUARD, RBW>(p, acc, m_w, n_w, n_blk, lane);
+            else g6_direct_tail<ACT, true, false, 1, GUARD, RBW>(p, acc, m_w, n_w, n_blk, lane);
         } else {
-            if (outf && outs) g6_direct_tail<ACT, false, true, 1, GUARD>(p, acc, m_w, n_w, lane);
-            else if (outf) g6_direct_tail<ACT, false, true, 0, GUARD>(p, acc, m_w, n_w, lane);
-            else if (p.f16_out) g6_direct_tail<ACT, false, false, 2, GUARD>(p, acc, m_w, n_w, lane);
-            else g6_direct_tail<ACT, false, false, 1, GUARD>(p, acc, m_w, n_w, lane);
+            if (outf && outs) g6_direct_tail<ACT, false, true, 1, GUARD, RBW>(p, acc, m_w, n_w, n_blk, lane);
+            else if (outf) g6_direct_tail<ACT, false, true, 0, GUARD, RBW>(p, acc, m_w, n_w, n_blk, lane);
+            else if (p.f16_out) g6_direct_tail<ACT, false, false, 2, GUARD, RBW>(p, acc, m_w, n_w, n_blk, lane);
+            else g6_direct_tail<ACT, false, false, 1, GUARD, RBW>(p, acc, m_w, n_w, n_blk, lane);
         }
     } else {
-        if (res) g6_direct_tail<ACT, true, true, 0, GUARD>(p, acc, m_w, n_w, lane);
-        else if (outs && !outf && p.f16_out) g6_direct_tail<ACT, false, false, 2, GUARD>(p, acc, m_w, n_w, lane);
-        else if (outs && !outf) g6_direct_tail<ACT, false, false, 1, GUARD>(p, acc, m_w, n_w, lane);
-        else if (outf && !outs) g6_direct_tail<ACT, false, true, 0, GUARD>(p, acc, m_w, n_w, lane);
-        else g6_direct_tail<ACT, false, true, 1, GUARD>(p, acc, m_w, n_w, lane);
+        if (res) g6_direct_tail<ACT, true, true, 0, GUARD, RBW>(p, acc, m_w, n_w, n_blk, lane);
+        else if (outs && !outf && p.f16_out) g6_direct_tail<ACT, false, false, 2, GUARD, RBW>(p, acc, m_w, n_w, n_blk, lane);
+        else if (outs && !outf) g6_direct_tail<ACT, false, false, 1, GUARD, RBW>(p, acc, m_w, n_w, n_blk, lane);
+        else if (outf && !outs) g6_direct_tail<ACT, false, true, 0, GUARD, RBW>(p, acc, m_w, n_w, n_blk, lane);
+        else g6_direct_tail<ACT, false, true, 1, GUARD, RBW>(p, acc, m_w, n_w, n_blk, lane);
     }
 }
 
-F5_DEVICE void g6_direct_epilogue(const GemmArgs& p, f32x4 (&acc)[8][4], int m0, int n0, int m_w, int n_w, int lane) {
-    const bool interior = m0 + Gemm6Cfg::BM <= p.M && n0 + Gemm6Cfg::BN <= p.N && !p.row_keep;   // workgroup-uniform
-#define G6_ACT(A)                                                            \
-    if (interior) g6_direct_variants<A, false>(p, acc, m_w, n_w, lane);      \
-    else g6_direct_variants<A, true>(p, acc, m_w, n_w, lane);
+template <int RBW>
+F5_DEVICE void g6_direct_epilogue(const GemmArgs& p, f32x4 (&acc)[RBW][4], int m0, int n0, int m_w, int n_w, int n_blk, int lane) {
+    const bool interior = m0 + Gemm6Cfg<RBW>::BM <= p.M && n0 + Gemm6Cfg<RBW>::BN <= p.N && !p.row_keep;   // workgroup-uniform
+#define G6_ACT(A)                                                                         \
+    if (interior) g6_direct_variants<A, false, RBW>(p, acc, m_w, n_w, n_blk, lane);       \
+    else g6_direct_variants<A, true, RBW>(p, acc, m_w, n_w, n_blk, lane);
     switch (p.act) {
         case ACT_GELU_TANH: G6_ACT(ACT_GELU_TANH) break;
         case ACT_GELU_ERF: G6_ACT(ACT_GELU_ERF) break;
@@ -247,10 +264,11 @@ F5_DEVICE void g6_direct_epilogue(const GemmArgs& p, f32x4 (&acc)[8][4], int m0,
 #undef G6_ACT
 }
 
-template <bool F16, int EPI>
+template <bool F16, int EPI, int RBW>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm6_kernel(const GemmArgs p, const int tiles_n, const int n_rows_w) {
-    using C = Gemm6Cfg;
-    using Q = C::Q;
+    using C = Gemm6Cfg<RBW>;
+    using Q = typename C::Q;
+    constexpr int QR = C::QR;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -265,13 +283,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // [0] start, [1] k-loop done, [2..5] quarter s of the epilogue done, [6] stores drained
     unsigned long long* const stamp = (p.stamps && (tid == 0 || tid == 256)) ? p.stamps + ((size_t)blockIdx.x * 2 + (tid >> 8)) * 8 : nullptr;
     if (stamp) stamp[0] = __builtin_amdgcn_s_memrealtime();
-    f32x4 acc[8][4];
-    if (swap) g6_kloop<F16, true>(p, smem, m0, n0, n_rows_w, wave, lane, acc);
-    else g6_kloop<F16, false>(p, smem, m0, n0, n_rows_w, wave, lane, acc);
+    f32x4 acc[RBW][4];
+    if (swap) g6_kloop<F16, true, RBW>(p, smem, m0, n0, n_rows_w, wave, lane, acc);
+    else g6_kloop<F16, false, RBW>(p, smem, m0, n0, n_rows_w, wave, lane, acc);
     if (stamp) stamp[1] = __builtin_amdgcn_s_memrealtime();
-
+    // rows of the LDS image this tile owns: all of them, or 176 of the 192 (the last row block of the second wave group is the next tile's)
+    const int m_end = min(p.M, m0 + C::BM);
     if constexpr (EPI == EPI_GENERIC) {
-        g6_direct_epilogue(p, acc, m0, n0, m0 + wr * 128, n0 + wc * 64, lane);
+        const int n_blk = min(RBW, (C::BM - wr * RBW * 16) / 16);
+        g6_direct_epilogue<RBW>(p, acc, m0, n0, m0 + wr * RBW * 16, n0 + wc * 64, n_blk, lane);
         if (stamp) {
             stamp[2] = stamp[3] = stamp[4] = stamp[5] = __builtin_amdgcn_s_memrealtime();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -279,40 +299,43 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
         return;
     }
-    // QKV epilogue: four quarters of 64 rows through one slab that aliases the dead ring; the row phases are gemm5's
+    // QKV epilogue: four quarters of QR row blocks through one slab that aliases the dead ring; the row phases are gemm5's, which bound
+    // their stores by p.M: they see the tile's own end instead
+    GemmArgs pe = p;
+    pe.M = m_end;
     float* slab = reinterpret_cast<float*>(smem);
-    auto write_rows = [&](auto half_t) {   // SWAP layout -> row-major slab [64 tokens][256 features]
+    auto write_rows = [&](auto half_t) {   // SWAP layout -> row-major slab [16 QR tokens][256 features]
         constexpr int H = decltype(half_t)::value;
 #pragma unroll
-        for (int i = 0; i < 4; i++)
+        for (int i = 0; i < QR; i++)
 #pragma unroll
-            for (int j = 0; j < 4; j++) *reinterpret_cast<f32x4*>(slab + (i * 16 + fr) * Q::SLD + wc * 64 + j * 16 + fq * 4) = acc[H * 4 + i][j];
+            for (int j = 0; j < 4; j++) *reinterpret_cast<f32x4*>(slab + (i * 16 + fr) * Q::SLD + wc * 64 + j * 16 + fq * 4) = acc[H * QR + i][j];
     };
-    auto write_cols = [&](auto half_t) {   // !SWAP layout -> transposed slab [256 features][64 tokens], + bias (V tiles)
+    auto write_cols = [&](auto half_t) {   // !SWAP layout -> transposed slab [256 features][16 QR tokens], + bias (V tiles)
         constexpr int H = decltype(half_t)::value;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const float b1 = p.bias[n0 + wc * 64 + j * 16 + fr];
 #pragma unroll
-            for (int i = 0; i < 4; i++)
-                *reinterpret_cast<f32x4*>(slab + (wc * 64 + j * 16 + fr) * Q::SLDT + i * 16 + fq * 4) = acc[H * 4 + i][j] + (f32x4){b1, b1, b1, b1};
+            for (int i = 0; i < QR; i++)
+                *reinterpret_cast<f32x4*>(slab + (wc * 64 + j * 16 + fr) * Q::SLDT + i * 16 + fq * 4) = acc[H * QR + i][j] + (f32x4){b1, b1, b1, b1};
         }
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
 #pragma unroll 1
     for (int s = 0; s < 4; s++) {
-        const int mq = m0 + s * 64;
-        if (mq >= p.M) break;                                       // (workgroup-uniform: quarters past the last row)
+        const int mq = m0 + s * (QR * 16);
+        if (mq >= m_end) break;                                     // (workgroup-uniform: quarters past the last row)
         const bool mine = wr == (s >> 1);
         if (swap) {
             if (mine) { if (s & 1) write_rows(I1{}); else write_rows(I0{}); }
             __syncthreads();
-            g5_qk_rows<4, 16, 3>(p, slab, mq, n0, wave, lane);
+            g5_qk_rows<QR, 16, 3>(pe, slab, mq, n0, wave, lane);
         } else {
             if (mine) { if (s & 1) write_cols(I1{}); else write_cols(I0{}); }
             __syncthreads();
-            g5_v_rows<4, 16, 3>(p, slab, mq, n0, 0, wave, lane);
+            g5_v_rows<QR, 16, 3>(pe, slab, mq, n0, 0, wave, lane);
         }
         __syncthreads();                                            // the slab is free for the next quarter
         if (stamp) stamp[2 + s] = __builtin_amdgcn_s_memrealtime();
@@ -323,13 +346,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
-template <bool F16, int EPI>
+template <bool F16, int EPI, int RBW>
 static hipError_t launch_gemm6_t(const GemmArgs& a, int n_pad, hipStream_t st) {
-    using C = Gemm6Cfg;
+    using C = Gemm6Cfg<RBW>;
     if (n_pad % C::BN || a.K % 64 || a.K < 64 || (EPI == EPI_QKV && a.D % C::BN)) return hipErrorInvalidValue;
     static unsigned attr_mask = 0;
-    if (hipError_t e = f5_set_lds_attr(reinterpret_cast<const void*>(&gemm6_kernel<F16, EPI>), C::LDS, attr_mask); e != hipSuccess) return e;
+    if (hipError_t e = f5_set_lds_attr(reinterpret_cast<const void*>(&gemm6_kernel<F16, EPI, RBW>), C::LDS, attr_mask); e != hipSuccess) return e;
     const int tiles_m = (a.M + C::BM - 1) / C::BM, tiles_n = n_pad / C::BN;
-    hipLaunchKernelGGL((gemm6_kernel<F16, EPI>), dim3(tiles_m * tiles_n), dim3(512), C::LDS, st, a, tiles_n, n_pad);
+    hipLaunchKernelGGL((gemm6_kernel<F16, EPI, RBW>), dim3(tiles_m * tiles_n), dim3(512), C::LDS, st, a, tiles_n, n_pad);
     return hipGetLastError();
 }

@@ -13,8 +13,16 @@ hipError_t f5_launch_gemm3(int prec, int epi, int bn, const GemmArgs& a, int m_p
 // gemm5.h: exact-fit (16 rb) x (16 cb) tiles, 64-deep k-steps, fp16 operands
 hipError_t f5_launch_gemm5_generic(const GemmArgs& a, int rb, int cb, int n_pad, hipStream_t st);
 hipError_t f5_launch_gemm5_qkv(const GemmArgs& a, int rb, int cb, int n_pad, hipStream_t st);
-// gemm6.h: 256 x 256 x 64 ping-pong tiles, fp16 operands: the batch-mode shapes (hipErrorInvalidValue: n_pad % 256, K % 64, D % 256)
-hipError_t f5_launch_gemm6(int epi, const GemmArgs& a, int n_pad, hipStream_t st);
+// gemm6.h: ping-pong tiles of `rows` (256 or 176) x 256 columns, fp16 operands: the batch-mode shapes (hipErrorInvalidValue: n_pad % 256, K % 64, D % 256)
+hipError_t f5_launch_gemm6(int epi, int rows, const GemmArgs& a, int n_pad, hipStream_t st);
+// gemm6 tile height: fewest (rounds on the 256 CUs) x (cost of a tile: a 176-row tile measures ~ 0.85 of a 256-row one -- k-loop 22.0 against
+// 26.0 us at K = 1024, profiles/r03_gemm6_stamps_*.txt -- so it pays where it saves a round: out / FF2 at the C3 share, not FF1 / QKV); 0 = too few tiles
+static inline int gemm6_choose_rows(int m_rows, int n_pad) {
+    const long long t256 = (long long)((m_rows + 255) / 256) * (n_pad / 256), t176 = (long long)((m_rows + 175) / 176) * (n_pad / 256);
+    if (t256 < 224 && t176 < 224) return 0;
+    const double c256 = (double)((t256 + 255) / 256), c176 = 0.85 * (double)((t176 + 255) / 256);
+    return c176 < c256 ? 176 : 256;
+}
 // a residual GEMM (64-column tiles of a 1024-wide stream) with the LayerNorm that follows it fused behind the epilogue (GemmArgs::ln ...):
 // one resident wave of workgroups, 16 column tiles per row slab; hipErrorInvalidValue otherwise.  Experiments builds only (measured
 // slower than the two launches it replaces).
