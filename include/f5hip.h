@@ -103,8 +103,17 @@ int f5hip_dit_set_ode_method(f5hip_dit* m, int32_t method);
  * the end: the same sums in a different fp32 association, so a sequence's output can differ in the last bits from what it gets inside a
  * larger batch (the softmax offsets and the fp16 probabilities are the same in every variant).  In the mixed GEMM mode any last-bit
  * difference grows to that mode's rounding-noise floor over a forward pass (profiles/r03_attn_mode_tapdiff.txt).  1: shape-invariant arithmetic -- every variant adds every query's terms in one order, so a
- * sequence's output does not depend on what it is batched with (bit-identical); ~3 % slower at batch 1.  Process-wide. */
+ * sequence's output does not depend on what it is batched with (bit-identical); ~3 % slower at batch 1.
+ * f5hip_set_attention_shape_invariant sets the PROCESS DEFAULT; f5hip_dit_set_attention_shape_invariant sets it for one handle
+ * (1 / 0, or -1 = follow the process default again), so two handles in one process -- a serving handle that promises batch-independent
+ * results next to a latency-bound one -- do not share the setting. */
 int f5hip_set_attention_shape_invariant(int32_t on);
+int f5hip_dit_set_attention_shape_invariant(f5hip_dit* m, int32_t on);
+/* Per-handle profiling: like f5hip_set_profiling / f5hip_get_profile below, but the HIP-event spans, their pool and the totals belong to this
+ * handle alone (a handle that never called it records into the process-wide state when that is enabled).  Calls on one handle are still one
+ * at a time; calls on different handles may come from different threads. */
+int f5hip_dit_set_profiling(f5hip_dit* m, int32_t enabled);
+int f5hip_dit_get_profile(f5hip_dit* m, const char* kernel_class, double* total_ms, int64_t* launches);
 /* Per-kernel timing of the last f5hip_cfm_sample call when profiling was enabled with
  * f5hip_set_profiling(1): average milliseconds per launch of the named kernel class
  * ("gemm", "attn", "ln", "other") measured with HIP events on the launch stream, and launch counts. */

@@ -137,6 +137,23 @@ def test_bench_under_torch_distributed_run():
     assert d["n_gpus"] == 2 and d["value"] == 3.0 and d["steps"] == 3
 
 
+def test_bench_launcher_does_not_hang_when_a_rank_dies():
+    """a rank that exits before its first collective leaves the others blocked in it; the launcher polls every child, gives the
+    survivors a grace period, terminates them and returns non-zero, with the dead rank's stderr kept (gpurun_out/bench_rank<r>.err)."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env["F5HIP_BENCH_FAKE"] = "1"
+    env["F5HIP_BENCH_FAKE_FAIL_RANK"] = "1"
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env, capture_output=True,
+                       text=True, timeout=180)
+    assert r.returncode != 0 and time.time() - t0 < 120
+    assert "rank 1 exit code 3" in r.stderr and "fake failure of rank 1" in r.stderr
+
+
 def test_strong_mode_sharding_covers_every_unit_once():
     from tts_indic_server_f5_amd.sharding import shard_units, unit_cost
     frames = [1404] * 64

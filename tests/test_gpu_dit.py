@@ -278,3 +278,35 @@ def test_batch_of_copies_equals_single(base_model, attn_shape_invariant):
     four_d, _ = base_model.sample(cond.expand(4, -1, -1), text.expand(4, -1), 1404, steps=2, cfg_strength=2.0, sway_sampling_coef=-1.0,
                                   y0=y0.expand(4, -1, -1))
     assert _report("default mode: item of a batch vs the same utterance alone", four_d[2], fast[0]) < bound
+
+
+def test_two_handles_keep_their_own_attention_mode_and_profile():
+    """Per-handle state (include/f5hip.h: f5hip_dit_set_attention_shape_invariant / f5hip_dit_set_profiling): two samplers in one process,
+    one shape-invariant (what serve.TTSManager sets) and one on the fastest kernel per shape, driven alternately.  Each keeps its own
+    arithmetic -- the invariant one reproduces the item of a batch bit for bit, the other one takes the balanced kernel and differs -- and
+    its own HIP-event totals (launches of the other handle are not counted; a handle that never enabled profiling has none)."""
+    from tts_indic_server_f5_amd._lib import F5HipError
+    from tts_indic_server_f5_amd.model import F5TTS_BASE, F5HipModel
+    sd = synth.dit_state_dict()
+    inv = F5HipModel(F5TTS_BASE, sd, attn_shape_invariant=True)
+    fast = F5HipModel(F5TTS_BASE, sd, attn_shape_invariant=False)
+    gc = torch.Generator().manual_seed(14)
+    cond = torch.randn(1, 469, 100, generator=gc)
+    text = synth.text_ids()
+    y0 = synth.noise(1404, 0)[None]
+    kw = dict(steps=2, cfg_strength=2.0, sway_sampling_coef=-1.0)
+    inv.set_profiling(True)
+    a1, _ = inv.sample(cond, text, 1404, y0=y0, **kw)
+    b1, _ = fast.sample(cond, text, 1404, y0=y0, **kw)
+    prof = inv.get_profile()
+    a4, _ = inv.sample(cond.expand(4, -1, -1), text.expand(4, -1), 1404, y0=y0.expand(4, -1, -1), **kw)
+    b2, _ = fast.sample(cond, text, 1404, y0=y0, **kw)
+    a2, _ = inv.sample(cond, text, 1404, y0=y0, **kw)
+    assert torch.equal(a1, a2) and torch.equal(b1, b2)                       # interleaving changes nothing
+    assert _report("invariant handle: item of a batch vs alone", a4[1], a1[0]) == 0.0
+    d = _report("fast handle vs invariant handle, same utterance", b1[0], a1[0])
+    assert 0.0 < d < 1e-3                                                    # another kernel, same function (tests above bound it per mode)
+    assert prof["attn"]["launches"] == 2 * 22 and prof["ln"]["launches"] > 0 and prof["gemm"]["total_ms"] > 0   # ONE call of `inv`, none of `fast`
+    with pytest.raises(F5HipError):
+        fast.get_profile()
+    inv.set_profiling(False)

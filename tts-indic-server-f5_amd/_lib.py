@@ -44,6 +44,9 @@ SYMBOLS = {
     "f5hip_cfm_sample_masked": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                           C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),
     "f5hip_dit_set_ode_method": (C.c_int, [C.c_void_p, C.c_int32]),
+    "f5hip_dit_set_attention_shape_invariant": (C.c_int, [C.c_void_p, C.c_int32]),
+    "f5hip_dit_set_profiling": (C.c_int, [C.c_void_p, C.c_int32]),
+    "f5hip_dit_get_profile": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "f5hip_set_profiling": (C.c_int, [C.c_int32]),
     "f5hip_set_attention_shape_invariant": (C.c_int, [C.c_int32]),
     "f5hip_get_profile": (C.c_int, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

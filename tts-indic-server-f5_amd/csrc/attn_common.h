@@ -19,6 +19,7 @@ struct AttnArgs {
     __bf16* out_lo;     // may be null
     int f16_out;        // 1: out_hi receives one fp16 plane (A operand of the fp16 out-projection GEMM)
     unsigned long long* dbg;   // diagnostics (attn3): per-phase s_memtime totals of wave 0 of workgroup (0,0,0), or null
+    int shape_invariant;       // host side (kernel choice, tu_attn.hip): 1 = one association for every launch shape, 0 = fastest kernel per shape, -1 = the process default
 };
 
 F5_DEVICE int lds_off128(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }

@@ -38,6 +38,9 @@ struct f5hip_dit {
 #ifdef F5HIP_EXPERIMENTS
     StreamKWs sk;         // stream-K partial-tile slots + flags (experiments/gemm4.h), owned by the handle: launches of one handle are stream-ordered
 #endif
+    // per-handle settings (the process-wide setters are only their defaults)
+    int attn_invariant = -1;          // f5hip_dit_set_attention_shape_invariant: -1 = follow f5hip_set_attention_shape_invariant
+    ProfState* prof = nullptr;        // f5hip_dit_set_profiling: this handle's own HIP-event spans and totals (null: the process-wide state)
     bool blk_f16 = false; // gemm_planes == 3: transformer-block GEMMs (QKV, out, FF1, FF2) take one fp16 plane per operand
     bool skip_f16 = false; // UNetT (experiment, F5HIP_UNETT_SKIP_F16=1): the U-skip projections too
     // LayerNorm fused behind the residual GEMMs (gemm5 LNE kernels: experiments builds only, measured slower): per-handle arrival
@@ -151,6 +154,7 @@ void f5hip_dit_destroy(f5hip_dit* m) {
     streamk_ws_free(m->sk);
 #endif
     dev_free(m->meta);
+    delete m->prof;
     delete m;
 }
 
@@ -805,6 +809,7 @@ static int launch_attention(f5hip_dit* m, hipStream_t st) {
     AttnArgs at; memset(&at, 0, sizeof(at));
     at.qk = m->qk; at.vt = m->vt; at.D = c.dim; at.ldvt = m->Rtot; at.seq_row0 = m->d_seq_row0; at.seq_len = m->d_seq_len;
     at.seq_kvlen = m->d_seq_kvlen; at.out_hi = m->ao.hi; at.out_lo = m->nsplit == 2 ? m->ao.lo : nullptr; at.f16_out = m->blk_f16 ? 1 : 0;
+    at.shape_invariant = m->attn_invariant;
     int n_att = m->n_seq;
     if (m->arch == 2) {   // joint attention: audio and text queries of a sequence over its audio keys followed by its text keys
         at.seq_row0 = m->d_j_row0; at.seq_len = m->d_j_len; at.seq_kvlen = m->d_j_kvlen;
@@ -1096,6 +1101,7 @@ int f5hip_dit_forward(f5hip_dit* m, int32_t n_seq, const int32_t* seq_len, const
                       const uint8_t* drop_text, int32_t n_blocks, float* out_dev, float* h_out_dev, void* stream) {
     if (!m || !m->finalized) return fail(-1, "model not finalized");
     if (n_seq <= 0 || !seq_len || !x_dev || !cond_dev || !text) return fail(-1, "dit_forward: bad argument");
+    ProfScope prof_scope(m->prof);
     hipStream_t st = (hipStream_t)stream;
     std::vector<SeqDesc> seqs(n_seq);
     int f0 = 0;
@@ -1151,6 +1157,25 @@ int f5hip_set_attention_shape_invariant(int32_t on) {
     return 0;
 }
 
+int f5hip_dit_set_attention_shape_invariant(f5hip_dit* m, int32_t on) {
+    if (!m) return fail(-1, "null model");
+    m->attn_invariant = on < 0 ? -1 : (on != 0);
+    return 0;
+}
+
+int f5hip_dit_set_profiling(f5hip_dit* m, int32_t enabled) {
+    if (!m) return fail(-1, "null model");
+    if (!m->prof) m->prof = new ProfState();
+    m->prof->set(enabled != 0);
+    return 0;
+}
+
+int f5hip_dit_get_profile(f5hip_dit* m, const char* kernel_class, double* total_ms, int64_t* launches) {
+    if (!m || !kernel_class) return fail(-1, "dit_get_profile: bad argument");
+    if (!m->prof) return fail(-1, "dit_get_profile: f5hip_dit_set_profiling was never called on this handle");
+    return m->prof->get(kernel_class, total_ms, launches);
+}
+
 int f5hip_dit_set_ode_method(f5hip_dit* m, int32_t method) {
     if (!m) return fail(-1, "null model");
     if (method != 0 && method != 1) return fail(-1, "ode method %d: 0 = euler, 1 = midpoint", method);
@@ -1164,6 +1189,7 @@ int f5hip_cfm_sample_masked(f5hip_dit* m, int32_t n_utt, const int32_t* dur, con
     if (!m || !m->finalized) return fail(-1, "model not finalized");
     if (n_utt <= 0 || !dur || !cond_dev || !cond_mask || !text || !y0_dev || !t_grid || !out_dev || steps <= 0)
         return fail(-1, "cfm_sample: bad argument");
+    ProfScope prof_scope(m->prof);
     hipStream_t st = (hipStream_t)stream;
     const bool use_cfg = !(cfg_strength < 1e-5f);
     const int mel = m->cfg.mel_dim;

@@ -5,6 +5,7 @@
 #include <stdio.h>
 
 #include <algorithm>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -105,54 +106,80 @@ static int pack_linear(PackedW& out, const float* w, int N, int K, int ldw, cons
 enum { PROF_GEMM = 0, PROF_ATTN = 1, PROF_LN = 2, PROF_OTHER = 3, PROF_VOCOS = 4, PROF_N = 5 };
 static const char* g_prof_names[PROF_N] = {"gemm", "attn", "ln", "other", "vocos"};
 struct ProfSpan { int cls; hipEvent_t a, b; };
-static bool g_prof_on = false;
-static std::vector<ProfSpan> g_prof_spans;
-static std::vector<hipEvent_t> g_prof_pool;
-static double g_prof_ms[PROF_N];
-static long long g_prof_cnt[PROF_N];
-static int g_prof_open = 0;
+// One profiling state per owner: the process-wide default (f5hip_set_profiling / f5hip_get_profile) and one per sampler handle that asked for
+// its own (f5hip_dit_set_profiling).  The ABI entry points select the state of their handle for the calling THREAD (ProfScope), so two
+// handles driven from two threads never share spans, pools or totals.
+struct ProfState {
+    std::mutex mu;   // the process-wide state can be reached from several threads (handles without a state of their own)
+    bool on = false;
+    std::vector<ProfSpan> spans;
+    std::vector<hipEvent_t> pool;
+    double ms[PROF_N] = {0, 0, 0, 0, 0};
+    long long cnt[PROF_N] = {0, 0, 0, 0, 0};
+    int open = 0;
+    void collect() {
+        for (auto& s : spans) {
+            float t = 0.0f;
+            (void)hipEventSynchronize(s.b);
+            if (hipEventElapsedTime(&t, s.a, s.b) == hipSuccess) { ms[s.cls] += t; cnt[s.cls]++; }
+            pool.push_back(s.a); pool.push_back(s.b);
+        }
+        spans.clear();
+    }
+    void set(bool enabled) {
+        std::lock_guard<std::mutex> lk(mu);
+        collect();
+        on = enabled;
+        for (int i = 0; i < PROF_N; i++) { ms[i] = 0.0; cnt[i] = 0; }
+    }
+    int get(const char* kernel_class, double* total_ms, int64_t* launches) {
+        std::lock_guard<std::mutex> lk(mu);
+        collect();
+        for (int i = 0; i < PROF_N; i++)
+            if (!strcmp(kernel_class, g_prof_names[i])) {
+                if (total_ms) *total_ms = ms[i];
+                if (launches) *launches = cnt[i];
+                return 0;
+            }
+        return fail(-1, "unknown kernel class %s", kernel_class);
+    }
+    ~ProfState() { for (hipEvent_t e : pool) (void)hipEventDestroy(e); }
+};
+static ProfState g_prof_default;
+static thread_local ProfState* t_prof = &g_prof_default;
+struct ProfScope {   // selects `p` (a handle's own state; null = leave the thread on what it has) for the current thread until the scope ends
+    ProfState* prev;
+    explicit ProfScope(ProfState* p) : prev(t_prof) { if (p) t_prof = p; }
+    ~ProfScope() { t_prof = prev; }
+};
 
-static hipEvent_t prof_event() {
-    if (!g_prof_pool.empty()) { hipEvent_t e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
+static hipEvent_t prof_event(ProfState& ps) {
+    if (!ps.pool.empty()) { hipEvent_t e = ps.pool.back(); ps.pool.pop_back(); return e; }
     hipEvent_t e;
     (void)hipEventCreate(&e);
     return e;
 }
 static void prof_begin(int cls, hipStream_t st) {
-    if (!g_prof_on) return;
-    if (g_prof_open++) return;   // nested spans are attributed to the outer class
-    ProfSpan s; s.cls = cls; s.a = prof_event(); s.b = prof_event();
+    ProfState& ps = *t_prof;
+    if (!ps.on) return;
+    std::lock_guard<std::mutex> lk(ps.mu);
+    if (ps.open++) return;   // nested spans are attributed to the outer class
+    ProfSpan s; s.cls = cls; s.a = prof_event(ps); s.b = prof_event(ps);
     (void)hipEventRecord(s.a, st);
-    g_prof_spans.push_back(s);
+    ps.spans.push_back(s);
 }
 static void prof_end(int cls, hipStream_t st) {
     (void)cls;
-    if (!g_prof_on) return;
-    if (--g_prof_open) return;
-    (void)hipEventRecord(g_prof_spans.back().b, st);
-}
-static void prof_collect() {
-    for (auto& s : g_prof_spans) {
-        float ms = 0.0f;
-        (void)hipEventSynchronize(s.b);
-        if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) { g_prof_ms[s.cls] += ms; g_prof_cnt[s.cls]++; }
-        g_prof_pool.push_back(s.a); g_prof_pool.push_back(s.b);
-    }
-    g_prof_spans.clear();
+    ProfState& ps = *t_prof;
+    if (!ps.on) return;
+    std::lock_guard<std::mutex> lk(ps.mu);
+    if (--ps.open) return;
+    (void)hipEventRecord(ps.spans.back().b, st);
 }
 extern "C" int f5hip_set_profiling(int32_t enabled) {
-    prof_collect();
-    g_prof_on = enabled != 0;
-    for (int i = 0; i < PROF_N; i++) { g_prof_ms[i] = 0.0; g_prof_cnt[i] = 0; }
+    g_prof_default.set(enabled != 0);
     return 0;
 }
 extern "C" int f5hip_get_profile(const char* kernel_class, double* total_ms, int64_t* launches) {
-    prof_collect();
-    for (int i = 0; i < PROF_N; i++)
-        if (!strcmp(kernel_class, g_prof_names[i])) {
-            if (total_ms) *total_ms = g_prof_ms[i];
-            if (launches) *launches = g_prof_cnt[i];
-            return 0;
-        }
-    return fail(-1, "unknown kernel class %s", kernel_class);
+    return g_prof_default.get(kernel_class, total_ms, launches);
 }

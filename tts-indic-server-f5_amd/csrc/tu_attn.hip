@@ -18,7 +18,7 @@
 // feeding two MFMAs; F5HIP_ATTN_QB=2): parity-tested and measured slower -- 38.8 us against 35.4 at C2, 225 against 186 at 16 x 1404
 // (profiles/r02_attn_bench.txt): hipcc parks half of its score blocks in AGPRs (32 v_accvgpr_read per tile) and a lone in-order wave cannot
 // cover its own waits, which two waves per SIMD do for each other -- and F5HIP_ATTN_BAL=0 (the 6-wave form, for A/B timing).
-static int g_attn_shape_invariant = 0;   // f5hip_set_attention_shape_invariant
+static int g_attn_shape_invariant = 0;   // f5hip_set_attention_shape_invariant: the default of launches whose AttnArgs::shape_invariant is -1
 void f5_set_attn_shape_invariant(int on) { g_attn_shape_invariant = on != 0; }
 
 template <bool SEG2>
@@ -54,7 +54,8 @@ hipError_t f5_launch_attn3(const AttnArgs& a, int max_len, int heads, int n_seq,
     }
     const dim3 grid((max_len + 32 * best - 1) / (32 * best), heads, n_seq);
     const bool deep = best >= 6 && (long long)grid.x * grid.y * grid.z <= 256;
-    const bool bal = best == 6 && !no_bal && !g_attn_shape_invariant;
+    const bool invariant = a.shape_invariant < 0 ? g_attn_shape_invariant != 0 : a.shape_invariant != 0;
+    const bool bal = best == 6 && !no_bal && !invariant;
     if (a.seq_kv2_row0) attn3_launch<true>(a, best, deep, bal, grid, st);
     else attn3_launch<false>(a, best, deep, bal, grid, st);
     return hipGetLastError();

@@ -293,7 +293,7 @@ extern "C" int f5hip_op_attention(int32_t n_seq, const int32_t* seq_len, const i
     hipLaunchKernelGGL(op_pack_qkv_kernel, dim3(M_pad), dim3(256), 0, st, q_dev, k_dev, v_dev, D, d_rs, M_pad, qk, vt);
     AttnArgs at; memset(&at, 0, sizeof(at));
     at.qk = qk; at.vt = vt; at.D = D; at.ldvt = M_pad; at.seq_row0 = d_meta; at.seq_len = d_meta + n_seq; at.seq_kvlen = d_meta + 2 * n_seq;
-    at.out_hi = ohi; at.out_lo = olo;
+    at.out_hi = ohi; at.out_lo = olo; at.shape_invariant = -1;
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     hipError_t e = hipSuccess;
@@ -359,7 +359,7 @@ extern "C" int f5hip_op_joint_attention(int32_t n_seq, const int32_t* x_len, con
     AttnArgs at; memset(&at, 0, sizeof(at));
     at.qk = qk; at.vt = vt; at.D = D; at.ldvt = M_pad + 256; at.seq_row0 = d_meta; at.seq_len = d_meta + NS; at.seq_kvlen = d_meta + 2 * NS;
     at.seq_kv_row0 = d_meta + 3 * NS; at.seq_kv2_row0 = d_meta + 4 * NS; at.seq_kv2_len = d_meta + 5 * NS;
-    at.out_hi = ohi; at.out_lo = olo;
+    at.out_hi = ohi; at.out_lo = olo; at.shape_invariant = -1;
     const hipError_t e = f5_launch_attn3(at, max_len, heads, NS, st);
     if (e != hipSuccess) return fail(-7, "op_joint_attention launch: %s", hipGetErrorString(e));
     hipLaunchKernelGGL(op_unpack_planes_kernel, dim3(F), dim3(256), 0, st, ohi, olo, D, d_fr, out_dev);

@@ -278,9 +278,13 @@ def infer_requests(requests, model_obj, vocoder, mel_spec_type=mel_spec_type, ta
                    cross_fade_duration=cross_fade_duration, nfe_step=nfe_step, cfg_strength=cfg_strength,
                    sway_sampling_coef=sway_sampling_coef, speed=speed, fix_duration=fix_duration, device=None, tokenizer=text_to_tokens):
     """Several `infer_process()` calls as ONE sampler batch: `requests` = [(ref_audio, ref_text, gen_text)], each with its own
-    reference voice (a path, a (wave, sr) pair or a `PreparedVoice`); returns one (wave, sample_rate, spectrogram) triple per request, each equal to what `infer_process` returns for
-    that request alone (units keep the reference's batch-1 semantics, so the batch composition does not leak; noise is drawn unit by
-    unit in request order, i.e. the draws of the sequential calls).  This is what the serving queue (`serve.MicroBatcher`) and the
+    reference voice (a path, a (wave, sr) pair or a `PreparedVoice`); returns one (wave, sample_rate, spectrogram) triple per request, each what `infer_process` returns for
+    that request alone: units keep the reference's batch-1 semantics (no padding against each other, no shared mask), and noise is drawn
+    unit by unit in request order, i.e. the draws of the sequential calls.  Bit for bit this holds when the model handle runs the
+    shape-invariant attention arithmetic (`F5HipModel(attn_shape_invariant=True)`, what `serve.TTSManager.load` sets); in the default
+    mode a lone unit and the same unit inside a batch may take different attention kernels (same values to the last bits per launch, but
+    in the mixed GEMM mode last-bit differences grow to that mode's rounding-noise floor, 4.4e-4 rms after two Euler steps:
+    `profiles/r03_attn_mode_tapdiff.txt`; either result is within the 1e-3 bound of the reference).  This is what the serving queue (`serve.MicroBatcher`) and the
     multi-voice front-end hand to the GPU: the chunks of all waiting requests are packed back to back in one library call."""
     plans, flat_units, flat_cond, flat_audio = [], [], [], []
     for ref_audio, ref_text, gen_text in requests:

@@ -89,7 +89,8 @@ def _ptr(t):
 
 class F5HipModel:
     def __init__(self, arch: DiTArch | UNetTArch | MMDiTArch, state_dict: dict, vocab_char_map: dict | None = None, gemm_planes: int = 3,
-                 device: str | torch.device = "cuda:0", mel_spec_type: str = "vocos", odeint_kwargs: dict | None = None):
+                 device: str | torch.device = "cuda:0", mel_spec_type: str = "vocos", odeint_kwargs: dict | None = None,
+                 attn_shape_invariant: bool | None = None):
         # odeint_kwargs: CFM's constructor argument (F/model/cfm.py:37-41), dict(method="euler") by default; "midpoint" is the other
         # fixed-grid solver the reference names.  Adaptive torchdiffeq solvers are not offered.
         self.odeint_kwargs = dict(odeint_kwargs) if odeint_kwargs is not None else dict(method="euler")
@@ -120,6 +121,25 @@ class F5HipModel:
             _lib.check(self._lib.f5hip_dit_load_param(self._h, k.encode(), _ptr(a), a.size), "load_param " + k)
         _lib.check(self._lib.f5hip_dit_finalize(self._h), "f5hip_dit_finalize")
         _lib.check(self._lib.f5hip_dit_set_ode_method(self._h, 1 if method == "midpoint" else 0), "f5hip_dit_set_ode_method")
+        self.set_attention_shape_invariant(attn_shape_invariant)
+
+    def set_attention_shape_invariant(self, on: bool | None):
+        """This handle's attention arithmetic (include/f5hip.h): True = a sequence's output does not depend on what it is batched with,
+        False = the fastest kernel per launch shape, None = follow the process default (f5hip_set_attention_shape_invariant)."""
+        self.attn_shape_invariant = on
+        _lib.check(self._lib.f5hip_dit_set_attention_shape_invariant(self._h, -1 if on is None else int(bool(on))), "f5hip_dit_set_attention_shape_invariant")
+
+    def set_profiling(self, enabled: bool):
+        """HIP-event timing of this handle's launches, per kernel class (its own spans and totals: other handles are not counted)."""
+        _lib.check(self._lib.f5hip_dit_set_profiling(self._h, int(bool(enabled))), "f5hip_dit_set_profiling")
+
+    def get_profile(self) -> dict:
+        out = {}
+        for cls in ("gemm", "attn", "ln", "other"):
+            ms, n = C.c_double(0), C.c_int64(0)
+            _lib.check(self._lib.f5hip_dit_get_profile(self._h, cls.encode(), C.byref(ms), C.byref(n)), "f5hip_dit_get_profile")
+            out[cls] = {"total_ms": ms.value, "launches": n.value}
+        return out
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None

@@ -15,7 +15,10 @@ Differences, explicit:
   * `TTSManager(micro_batch=dict(max_requests=16, max_wait_ms=5))`: concurrent requests are collected for a few milliseconds and synthesized as ONE
     sampler batch (`infer.infer_requests`); with `ShardedSampler` as the model object that batch is dealt over the GPUs of the node
     (rank 0 serves HTTP and owns the queue, the other ranks sit in `rank_worker_loop`).  The reference serves one request at a
-    time on one GPU (`S/routes/speech.py:19-41`); results per request are the same.
+    time on one GPU (`S/routes/speech.py:19-41`).  A request's result does not depend on its batch: `load()` puts the model handle into
+    the library's shape-invariant attention mode (`batch_invariant=True`); without it the same utterance alone and inside a batch can take
+    different attention kernels, which agree to the last bits per launch but -- in the mixed GEMM mode -- drift apart to that mode's
+    rounding-noise floor over a sample (measured 4.4e-4 rms after two Euler steps, `profiles/r03_attn_mode_tapdiff.txt`).
 """
 
 import io
@@ -144,8 +147,9 @@ class TTSManager:
 
     def __init__(self, loader: Callable[[], tuple] | None = None, nfe_step: int = infer.nfe_step, cfg_strength: float = infer.cfg_strength,
                  sway_sampling_coef: float = infer.sway_sampling_coef, speed: float = infer.speed, mel_spec_type: str = "vocos",
-                 micro_batch: dict | None = None):
+                 micro_batch: dict | None = None, batch_invariant: bool = True):
         self.loader = loader
+        self.batch_invariant = batch_invariant   # False: leave the model's attention mode alone (fastest kernel per launch shape)
         self.micro_batch = micro_batch            # e.g. dict(max_requests=16, max_wait_ms=5): batch concurrent requests
         self.batcher: MicroBatcher | None = None
         self.model = None
@@ -169,6 +173,11 @@ class TTSManager:
                     raise ValueError("TTSManager.load needs a model object or a loader")
                 model_obj, vocoder = self.loader()
             self.model_obj, self.vocoder = model_obj, vocoder
+            # A served request must not depend on what it happened to be batched with: this handle runs the shape-invariant attention
+            # arithmetic (per-handle setting of the library, ~3 % at batch 1; other handles of the process keep theirs).
+            setter = getattr(getattr(model_obj, "local", model_obj), "set_attention_shape_invariant", None)
+            if callable(setter) and self.batch_invariant:
+                setter(True)
             self.model = self._call
             if self.micro_batch is not None:
                 self.batcher = MicroBatcher(self._run_batch, **self.micro_batch)
