@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""In-kernel time line of gemm5 (library built with F5HIP_BUILD_ABL=1): s_memrealtime stamps of every workgroup, printed by f5hip_op_gemm."""
+"""In-kernel time line of gemm5: s_memrealtime stamps of every workgroup, printed by f5hip_op_gemm / f5hip_op_qkv.  The W-direct kernels
+(FF1, QKV) stamp at run time; the others need a library built with F5HIP_BUILD_ABL=1."""
 import os
 import sys
 

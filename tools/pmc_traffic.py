@@ -5,7 +5,7 @@ x2; both counters are in KiB... as reported by rocprofv3 in this image: see `uni
 
   rocprofv3 --pmc FETCH_SIZE --kernel-trace -d gpurun_out/pmc_f -o f -- python3 tools/sample_pmc.py
   rocprofv3 --pmc WRITE_SIZE --kernel-trace -d gpurun_out/pmc_w -o w -- python3 tools/sample_pmc.py
-  python tools/pmc_traffic.py gpurun_out/pmc_f/f_results.db gpurun_out/pmc_w/w_results.db > profiles/r02_pmc_hbm_traffic.json"""
+  python tools/pmc_traffic.py gpurun_out/pmc_f/f_results.db gpurun_out/pmc_w/w_results.db > profiles/r03_pmc_hbm_traffic.json"""
 import json
 import sqlite3
 import sys
@@ -53,7 +53,7 @@ def main(fetch_db, write_db):
         n, fs = f[k]
         ws = w.get(k, [n, 0.0])[1]
         sys.stderr.write(f"{k[:70]:70s} {n:6d} {fs * 1024 * 2 / n / 1e6:10.2f} {ws * 1024 / max(w.get(k, [n])[0], 1) / 1e6:10.2f}\n")
-    res["source"] = "profiles/r02_pmc_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate passes over tools/sample_pmc.py, mean over the gemm5 launches (fp16 block GEMMs of the C2 workload)"
+    res["source"] = "profiles/r03_pmc_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate passes over tools/sample_pmc.py, mean over the gemm5 launches (fp16 block GEMMs of the C2 workload)"
     print(json.dumps(res, indent=1))
 
 

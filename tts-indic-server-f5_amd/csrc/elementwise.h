@@ -165,6 +165,18 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* w, int R,
     }
 }
 
+// one 16-bit plane [R_pad][ld] (row-major, K = C_pad contiguous) -> MFMA-fragment order (GemmArgs::Wf): thread = one 16-byte chunk
+__global__ __launch_bounds__(256) void pack_frag_kernel(const __bf16* src, int R_pad, int K, int ld, __bf16* dst) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;          // chunk index in the destination
+    const size_t n_chunks = (size_t)R_pad * K / 8;
+    if (idx >= n_chunks) return;
+    const int lane = (int)(idx & 63);
+    const size_t blk = idx >> 6;
+    const int kh = (int)(blk % (size_t)(K / 32)), cb = (int)(blk / (size_t)(K / 32));
+    const int row = cb * 16 + (lane & 15), k = kh * 32 + (lane >> 4) * 8;
+    *reinterpret_cast<u32x4*>(dst + idx * 8) = *reinterpret_cast<const u32x4*>(src + (size_t)row * ld + k);
+}
+
 // dst[f][0..C) = src[frame_row[f]][0..C): packed-row layout -> caller's frame order
 __global__ __launch_bounds__(128) void gather_rows_kernel(const float* src, int lds, int C, int n_frames, const int* frame_row,
                                                           float* dst, int ldd) {

@@ -134,7 +134,7 @@ f5hip_dit* f5hip_dit_create(const f5hip_dit_config* cfg) {
     return m;
 }
 
-static void free_packed(PackedW& w) { dev_free(w.hi); dev_free(w.lo); dev_free(w.bias); w = PackedW(); }
+static void free_packed(PackedW& w) { dev_free(w.hi); dev_free(w.lo); dev_free(w.bias); dev_free(w.frag); w = PackedW(); }
 
 void f5hip_dit_destroy(f5hip_dit* m) {
     if (!m) return;
@@ -306,11 +306,11 @@ int f5hip_dit_finalize(f5hip_dit* m) {
             memcpy(&wq[(size_t)i * D * D], w->data(), sizeof(float) * D * D);
             memcpy(&bq[(size_t)i * D], b->data(), sizeof(float) * D);
         }
-        if (pack_linear(m->wqkv[l], wq.data(), 3 * D, D, D, bq.data(), 128, m->blk_f16)) return -4;
+        if (pack_linear(m->wqkv[l], wq.data(), 3 * D, D, D, bq.data(), 128, m->blk_f16) || pack_frag(m->wqkv[l])) return -4;   // (+ fragment order: W-direct gemm5)
         GETP(wo, pa + "to_out.0.weight", (int64_t)D * D); GETP(bo, pa + "to_out.0.bias", D);
         if (pack_linear(m->wout[l], wo->data(), D, D, D, bo->data(), 128, m->blk_f16)) return -4;
         GETP(w1, pf + "ff.0.0.weight", (int64_t)F * D); GETP(b1, pf + "ff.0.0.bias", F);
-        if (pack_linear(m->wff1[l], w1->data(), F, D, D, b1->data(), 128, m->blk_f16)) return -4;
+        if (pack_linear(m->wff1[l], w1->data(), F, D, D, b1->data(), 128, m->blk_f16) || pack_frag(m->wff1[l])) return -4;
         GETP(w2, pf + "ff.2.weight", (int64_t)D * F); GETP(b2, pf + "ff.2.bias", D);
         if (pack_linear(m->wff2[l], w2->data(), D, F, F, b2->data(), 128, m->blk_f16)) return -4;
         if (m->arch == 2) {   // the text stream's own projections (Attention(context_dim=...), F/model/modules.py:365-374) and feed-forward
@@ -322,12 +322,12 @@ int f5hip_dit_finalize(f5hip_dit* m) {
                 memcpy(&wqc[(size_t)i * D * D], w->data(), sizeof(float) * D * D);
                 memcpy(&bqc[(size_t)i * D], b->data(), sizeof(float) * D);
             }
-            if (pack_linear(m->wqkv_c[l], wqc.data(), 3 * D, D, D, bqc.data(), 128, m->blk_f16)) return -4;
+            if (pack_linear(m->wqkv_c[l], wqc.data(), 3 * D, D, D, bqc.data(), 128, m->blk_f16) || pack_frag(m->wqkv_c[l])) return -4;
             if (l < c.depth - 1) {
                 GETP(woc, pa + "to_out_c.weight", (int64_t)D * D); GETP(boc, pa + "to_out_c.bias", D);
                 if (pack_linear(m->wout_c[l], woc->data(), D, D, D, boc->data(), 128, m->blk_f16)) return -4;
                 GETP(w1c, p + "ff_c.ff.0.0.weight", (int64_t)F * D); GETP(b1c, p + "ff_c.ff.0.0.bias", F);
-                if (pack_linear(m->wff1_c[l], w1c->data(), F, D, D, b1c->data(), 128, m->blk_f16)) return -4;
+                if (pack_linear(m->wff1_c[l], w1c->data(), F, D, D, b1c->data(), 128, m->blk_f16) || pack_frag(m->wff1_c[l])) return -4;
                 GETP(w2c, p + "ff_c.ff.2.weight", (int64_t)D * F); GETP(b2c, p + "ff_c.ff.2.bias", D);
                 if (pack_linear(m->wff2_c[l], w2c->data(), D, F, F, b2c->data(), 128, m->blk_f16)) return -4;
             }
@@ -508,7 +508,7 @@ static GemmArgs gemm_base(const Plane2& A, int lda, const PackedW& W, int M) {
     GemmArgs a;
     memset(&a, 0, sizeof(a));
     a.A[0] = A.hi; a.A[1] = A.lo; a.lda = lda;
-    a.W[0] = W.hi; a.W[1] = W.lo;
+    a.W[0] = W.hi; a.W[1] = W.lo; a.Wf = W.frag;
     a.M = M; a.N = W.n; a.K = W.k_pad; a.ldw = W.ld;
     a.bias = W.bias;
     return a;

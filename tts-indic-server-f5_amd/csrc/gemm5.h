@@ -51,8 +51,7 @@ struct Gemm5Cfg {
     static constexpr int NPAN = CB / 4;                   // 64-column panels
     static constexpr int RING = NST * STAGE, SLAB = BM * SLD * 4, SLAB_T = BN * SLDT * 4;
     static constexpr int LDS = RING > SLAB ? (RING > SLAB_T ? RING : SLAB_T) : (SLAB > SLAB_T ? SLAB : SLAB_T);
-    static_assert(LDS <= 160 * 1024, "tile does not fit the LDS");
-    static_assert(CB % 4 == 0, "column blocks must split over 64-column panels");
+    static_assert(CB % 4 == 0, "column blocks must split over 64-column panels");   // (LDS <= 160 KiB is checked where a kernel is launched: the W-direct kernels' ring holds A rows only)
 };
 
 // tile index of workgroup b: XCD-blocked when the grid divides over the 8 XCDs (speed only: any bijection is correct)
@@ -126,6 +125,98 @@ F5_DEVICE void g5_consume(const char* smem, int nk, int rb0, int cb0, int lane, 
     read_b(1, b_ptr(nk - 1, 1));
     half_step(ROLL, 0, a_ptr(nk - 1, 1));
     half_step(LAST, 1, nullptr);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// consumer k-loop with the W fragments STRAIGHT FROM GLOBAL MEMORY ("W-direct", round 3).  In the 1 x 4 consumer layout a wave's column
+// blocks are its own: nobody else in the workgroup multiplies those W rows, so staging them through LDS only costs -- half of the LDS-DMA
+// pieces of a 176 x 192 tile (the loaders' issue time, ~200 cycles per piece next to busy fragment reads, is what bounds that k-loop:
+// 0.94 us per k-step against 0.5 of MFMA work) and a fifth of the LDS reads.  The weights are kept a second time in FRAGMENT ORDER
+// (GemmArgs::Wf, packed once at load: block (16 columns, 32 k) = 64 lanes x 16 bytes, lane = (column & 15) + 16 (k chunk), blocks k-major
+// within a column block), so a fragment is ONE fully coalesced 1 KiB wave load.  Four half steps of fragments are in flight (L2 latency
+// ~1 us against ~0.25 us per half step): a ring of four register sets, hence the loop is unrolled over TWO k-steps (K % 128 == 0) and every
+// slot index is a compile-time constant; loads past the end re-read the last half step (branch-free).  The compiler counts vmcnt exactly:
+// these waves issue no other vector-memory instruction inside the loop.  Barrier protocol and the rolling A fragments: g5_consume's.
+// Registers: the 176 x 192 tile (132 accumulator registers + 48 of W fragments) has no room for g5_consume's eleven rolling A fragments, so
+// the row blocks of a half step go in TWO passes over a window of W1 = ceil(MRB / 2) fragments: behind the MFMAs of block i (pass 1) its
+// registers take block W1 + i of the SAME half step, behind those of pass 2 block i of the NEXT one.  Consequence for the ring: the second
+// half of k-step kt still reads stage kt AFTER barrier B_{kt+1}, so a stage is dead one barrier later than in g5_consume and the loaders
+// refill stage kt - 1 (not kt) behind B_{kt+1} -- the ring (A rows only: 22 KiB stages) is two stages deeper instead.
+template <bool F16, int BM, int STAGE, int NST, int MRB, int MCB, bool SWAP>
+F5_DEVICE void g5_consume_wd(const char* smem, const char* wf, size_t wf_jstride, int nk, int rb0, int lane, f32x4 (&acc)[MRB][MCB]) {
+    constexpr int W1 = (MRB + 1) / 2, W2 = MRB - W1;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int off0 = fr * 128 + ((fq ^ (fr >> 1)) << 4);
+#pragma unroll
+    for (int i = 0; i < MRB; i++)
+#pragma unroll
+        for (int j = 0; j < MCB; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bf16x8 fa[W1], fb[4][MCB];
+    const int h_last = 2 * nk - 1;
+    auto a_ptr = [&](int kt, int ks) { return smem + (kt % NST) * STAGE + rb0 * 2048 + (ks ? (off0 ^ 64) : off0); };
+    auto load_w = [&](auto slot_t, int h) {
+        constexpr int S = decltype(slot_t)::value;
+        const char* src = wf + (size_t)min(h, h_last) * 1024;
+#pragma unroll
+        for (int j = 0; j < MCB; j++) fb[S][j] = *reinterpret_cast<const bf16x8*>(src + j * wf_jstride);
+    };
+    // one half step: W fragments of slot S; sa_cur = this half step's A rows (blocks W1 .. of pass 2), sa_next = the next half step's
+    auto half_step = [&](auto slot_t, auto reload, const char* sa_cur, const char* sa_next) {
+        constexpr int S = decltype(slot_t)::value;
+        constexpr bool RELOAD = decltype(reload)::value;
+#pragma unroll
+        for (int i = 0; i < W1; i++) {
+#pragma unroll
+            for (int j = 0; j < MCB; j++)
+                acc[i][j] = SWAP ? mfma_16x16x32<F16>(fb[S][j], fa[i], acc[i][j]) : mfma_16x16x32<F16>(fa[i], fb[S][j], acc[i][j]);
+            if (i < W2) fa[i] = *reinterpret_cast<const bf16x8*>(sa_cur + (W1 + i) * 2048);
+            else if (RELOAD) fa[i] = *reinterpret_cast<const bf16x8*>(sa_next + i * 2048);
+        }
+#pragma unroll
+        for (int i = 0; i < W2; i++) {
+#pragma unroll
+            for (int j = 0; j < MCB; j++)
+                acc[W1 + i][j] = SWAP ? mfma_16x16x32<F16>(fb[S][j], fa[i], acc[W1 + i][j]) : mfma_16x16x32<F16>(fa[i], fb[S][j], acc[W1 + i][j]);
+            if (RELOAD) fa[i] = *reinterpret_cast<const bf16x8*>(sa_next + i * 2048);
+        }
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    using S2 = std::integral_constant<int, 2>;
+    using S3 = std::integral_constant<int, 3>;
+    constexpr std::integral_constant<bool, true> ROLL{};
+    constexpr std::integral_constant<bool, false> LAST{};
+    load_w(S0{}, 0); load_w(S1{}, 1); load_w(S2{}, 2); load_w(S3{}, 3);
+    __builtin_amdgcn_s_barrier();                              // B_0: k-step 0 landed
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < W1; i++) fa[i] = *reinterpret_cast<const bf16x8*>(a_ptr(0, 0) + i * 2048);
+    int kt = 0;
+    for (; kt + 2 < nk; kt += 2) {
+        const int h = 2 * kt;
+        half_step(S0{}, ROLL, a_ptr(kt, 0), a_ptr(kt, 1));
+        load_w(S0{}, h + 4);
+        __builtin_amdgcn_s_waitcnt(0xC07F);                    // lgkmcnt(0): every read issued so far has returned (stage kt - 1 is dead)
+        __builtin_amdgcn_s_barrier();                          // B_{kt+1}
+        asm volatile("" ::: "memory");
+        half_step(S1{}, ROLL, a_ptr(kt, 1), a_ptr(kt + 1, 0));
+        load_w(S1{}, h + 5);
+        half_step(S2{}, ROLL, a_ptr(kt + 1, 0), a_ptr(kt + 1, 1));
+        load_w(S2{}, h + 6);
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_s_barrier();                          // B_{kt+2}
+        asm volatile("" ::: "memory");
+        half_step(S3{}, ROLL, a_ptr(kt + 1, 1), a_ptr(kt + 2, 0));
+        load_w(S3{}, h + 7);
+    }
+    // the last two k-steps (kt = nk - 2): one barrier, no reload behind the last half step
+    half_step(S0{}, ROLL, a_ptr(kt, 0), a_ptr(kt, 1));
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_s_barrier();                              // B_{nk-1}
+    asm volatile("" ::: "memory");
+    half_step(S1{}, ROLL, a_ptr(kt, 1), a_ptr(kt + 1, 0));
+    half_step(S2{}, ROLL, a_ptr(kt + 1, 0), a_ptr(kt + 1, 1));
+    half_step(S3{}, LAST, a_ptr(kt + 1, 1), nullptr);
 }
 
 // consumers: accumulators -> slab.  ROWMAJOR: slab[token][feature] (stride SLD); else slab[feature][token] (stride SLDT, + bias: V blocks).
@@ -381,13 +472,15 @@ F5_DEVICE f32x4 g5_load_f4_agent(const float* ptr) {
     asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(ptr) : "memory");
     return v;
 }
-template <bool F16, int EPI, int RB, int CB, int WR, int NST, int ABL = 0, bool LNE = false>
+// WD: W fragments straight from global memory (g5_consume_wd): the ring holds A rows only; needs the 1 x 4 consumer layout, K % 128 == 0, p.Wf.
+template <bool F16, int EPI, int RB, int CB, int WR, int NST, int ABL = 0, bool LNE = false, bool WD = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm5_kernel(const GemmArgs p, const int tiles_n, const int n_rows_w) {
     using C = Gemm5Cfg<RB, CB, NST>;
-    constexpr int BM = C::BM, BN = C::BN, PIECES = C::PIECES, STAGE = C::STAGE;
+    static_assert(!WD || (WR == 1 && ABL == 0 && !LNE), "W-direct: 1 x 4 consumer layout, production kernels only");
+    constexpr int BM = C::BM, BN = C::BN, PIECES = WD ? BM / 8 : C::PIECES, STAGE = PIECES * 1024;
     constexpr int WC = 4 / WR;                                 // the 4 consumer waves tile the block grid WR (rows) x WC (columns)
     constexpr int MRB = (RB + WR - 1) / WR, MCB = CB / WC;
-    static_assert(CB % WC == 0 && NST >= 3 && NST <= 4, "bad tile configuration");
+    static_assert(CB % WC == 0 && NST >= 3 && (WD ? NST <= 6 : NST <= 4), "bad tile configuration");
     constexpr int P_HI = (PIECES + 3) / 4, P_LO = PIECES / 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -397,7 +490,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
     const int nk = p.K >> 6;
     unsigned long long ts[6] = {0, 0, 0, 0, 0, 0};
-#define G5_STAMP(I) if constexpr (ABL == 5) { if (tid == 0 || tid == 256) ts[I] = __builtin_amdgcn_s_memrealtime(); }
+    // time line: ABL == 5 builds keep the stamps in registers; the W-direct kernels write them straight to p.stamps when it is set (run time,
+    // tools/gemm5_stamps.py with F5HIP_GEMM5_STAMPS=1: no special build)
+    unsigned long long* const stamp_o = (WD && p.stamps && (tid == 0 || tid == 256)) ? p.stamps + ((size_t)blockIdx.x * 2 + (tid >> 8)) * 8 : nullptr;
+#define G5_STAMP(I) if constexpr (ABL == 5) { if (tid == 0 || tid == 256) ts[I] = __builtin_amdgcn_s_memrealtime(); } else if constexpr (WD) { if (stamp_o) stamp_o[I] = __builtin_amdgcn_s_memrealtime(); }
     G5_STAMP(0);
     // consumer geometry (also used by the epilogue): row blocks rb0 .. rb0 + nrb - 1, column blocks cb0 .. cb0 + MCB - 1
     const int cw = wave & 3;
@@ -405,7 +501,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int rb0 = (wr * RB) / WR, nrb = ((wr + 1) * RB) / WR - rb0;   // wave-uniform
     const int cb0 = wc * MCB;
     // all-V tiles of the QKV projection keep the token on the accumulator registers (their output is [feature][token])
-    const bool swap = !(EPI == EPI_QKV && n0 >= 2 * p.D);
+    // (W-direct kernels keep the SWAP layout for V tiles too: one k-loop instantiation instead of two -- the 176 x 192 QKV kernel has no
+    // registers to spare -- and the transposed slab is written with four scalar stores per block instead of one 16-byte store)
+    const bool swap = WD || !(EPI == EPI_QKV && n0 >= 2 * p.D);
     f32x4 acc[MRB][MCB];
 
     // Ring protocol.  All NST stages are filled up front.  Barrier B_{kt+1} sits between the two 32-deep halves of k-step kt: behind it
@@ -439,10 +537,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         };
         // this wave's pieces of a k-step have landed when at most `newer` younger k-steps of its own are still in flight
         auto wait_landed = [&](int newer) {
+            static_assert(5 * P_HI <= 63, "vmcnt immediate");
             if (mine == P_HI) {
-                if (newer >= 3) wait_vmcnt<3 * P_HI>(); else if (newer == 2) wait_vmcnt<2 * P_HI>(); else if (newer == 1) wait_vmcnt<P_HI>(); else wait_vmcnt<0>();
+                if (newer >= 5) wait_vmcnt<5 * P_HI>(); else if (newer == 4) wait_vmcnt<4 * P_HI>(); else
+                if (newer == 3) wait_vmcnt<3 * P_HI>(); else if (newer == 2) wait_vmcnt<2 * P_HI>(); else if (newer == 1) wait_vmcnt<P_HI>(); else wait_vmcnt<0>();
             } else {
-                if (newer >= 3) wait_vmcnt<3 * P_LO>(); else if (newer == 2) wait_vmcnt<2 * P_LO>(); else if (newer == 1) wait_vmcnt<P_LO>(); else wait_vmcnt<0>();
+                if (newer >= 5) wait_vmcnt<5 * P_LO>(); else if (newer == 4) wait_vmcnt<4 * P_LO>(); else
+                if (newer == 3) wait_vmcnt<3 * P_LO>(); else if (newer == 2) wait_vmcnt<2 * P_LO>(); else if (newer == 1) wait_vmcnt<P_LO>(); else wait_vmcnt<0>();
             }
         };
 #pragma unroll
@@ -451,11 +552,23 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         wait_landed(min(NST - 1, nk - 1));
         G5_STAMP(1);
         __builtin_amdgcn_s_barrier();                          // B_0
+        if constexpr (WD) {
+            // g5_consume_wd reads stage kt until B_{kt+2}: behind B_{kt+1} the free stage is that of k-step kt - 1
+            for (int kt = 0; kt + 1 < nk; kt++) {
+                wait_landed(min(NST - 3, nk - 2 - kt));        // k-step kt + 1 (issued so far: up to kt + NST - 2)
+                __builtin_amdgcn_s_barrier();                  // B_{kt+1}
+                if (kt >= 1 && kt - 1 + NST < nk) issue_tile(kt - 1 + NST);
+            }
+        } else
         for (int kt = 0; kt + 1 < nk; kt++) {
             wait_landed(min(NST - 2, nk - 2 - kt));            // k-step kt + 1 (k-steps kt + 2 .. kt + NST - 1 stay in flight)
             __builtin_amdgcn_s_barrier();                      // B_{kt+1}
             if (kt + NST < nk) issue_tile(kt + NST);
         }
+    } else if constexpr (WD) {
+        const size_t jstride = (size_t)(p.K >> 5) * 1024;      // bytes between the fragments of two column blocks
+        const char* wf = reinterpret_cast<const char*>(p.Wf) + (size_t)(n0 / 16 + cb0) * jstride + lane * 16;
+        g5_consume_wd<F16, BM, STAGE, NST, MRB, MCB, true>(smem, wf, jstride, nk, rb0, lane, acc);
     } else if (swap) {
         g5_consume<F16, BM, STAGE, NST, MRB, MCB, true, ABL>(smem, nk, rb0, cb0, lane, acc);
     } else {
@@ -472,12 +585,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         });
     } else if (swap) {
         // Q / K tile (possibly with V blocks behind the K | V boundary): row-major slab, rolled row phase; then the V blocks, if any
-        if (wave < 4) g5_write_slab<RB, CB, NST, WR, MRB, MCB, true, true>(acc, slab, rb0, nrb, cb0, lane, nullptr);
-        __syncthreads();                                           // E2
-        g5_qk_rows<RB, CB, NST>(p, slab, m0, n0, wave, lane);
-        const int f_lo = 2 * p.D - n0;                             // first V column of this tile (>= BN: none)
+        const int f_lo = max(0, 2 * p.D - n0);                     // first V column of this tile (>= BN: none; 0: an all-V tile of a W-direct kernel)
+        if (f_lo > 0) {                                            // (workgroup-uniform)
+            if (wave < 4) g5_write_slab<RB, CB, NST, WR, MRB, MCB, true, true>(acc, slab, rb0, nrb, cb0, lane, nullptr);
+            __syncthreads();                                       // E2
+            g5_qk_rows<RB, CB, NST>(p, slab, m0, n0, wave, lane);
+        }
         if (f_lo < BN) {                                           // (workgroup-uniform)
-            __syncthreads();                                       // the Q / K rows are done with the slab
+            if (f_lo > 0) __syncthreads();                         // the Q / K rows are done with the slab
             // column blocks at or behind the boundary (a multiple of 16) go to the transposed slab
             if (wave < 4) g5_write_slab<RB, CB, NST, WR, MRB, MCB, true, false>(acc, slab, rb0, nrb, cb0, lane, p.bias + n0, max(0, f_lo / 16 - cb0));
             __syncthreads();
@@ -521,6 +636,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         ln_finish<4>(p.ln, r1, lane, v1, sc, sh);
     }
     G5_STAMP(4);
+    if constexpr (WD) {
+        if (stamp_o) {
+            stamp_o[5] = __builtin_amdgcn_s_memrealtime();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            stamp_o[6] = __builtin_amdgcn_s_memrealtime();
+        }
+    }
     if constexpr (ABL == 5) {
         if (p.stamps && (tid == 0 || tid == 256)) {
             const unsigned long long t5 = __builtin_amdgcn_s_memrealtime();
@@ -534,14 +656,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #undef G5_STAMP
 }
 
-template <bool F16, int EPI, int RB, int CB, int WR, int NST, int ABL = 0, bool LNE = false>
+template <bool F16, int EPI, int RB, int CB, int WR, int NST, int ABL = 0, bool LNE = false, bool WD = false>
 static hipError_t launch_gemm5_t(const GemmArgs& a, int n_pad, hipStream_t st) {
     using C = Gemm5Cfg<RB, CB, NST>;
+    // LDS: the ring (A rows only with W-direct) or the epilogue slab that aliases it, whichever is larger
+    constexpr int ring = WD ? NST * (C::BM / 8) * 1024 : C::RING;
+    constexpr int lds = ring > C::SLAB ? (ring > C::SLAB_T ? ring : C::SLAB_T) : (C::SLAB > C::SLAB_T ? C::SLAB : C::SLAB_T);
+    static_assert(lds <= 160 * 1024, "tile does not fit the LDS");
+    if (WD && (!a.Wf || a.K % 128)) return hipErrorInvalidValue;
     static unsigned attr_mask = 0;
-    if (hipError_t e = f5_set_lds_attr(reinterpret_cast<const void*>(&gemm5_kernel<F16, EPI, RB, CB, WR, NST, ABL, LNE>), C::LDS, attr_mask); e != hipSuccess) return e;
+    if (hipError_t e = f5_set_lds_attr(reinterpret_cast<const void*>(&gemm5_kernel<F16, EPI, RB, CB, WR, NST, ABL, LNE, WD>), lds, attr_mask); e != hipSuccess) return e;
     const int tiles_m = (a.M + C::BM - 1) / C::BM, tiles_n = n_pad / C::BN;
     if (LNE && (tiles_n != 16 || !a.ln_sync || !a.ln_err || a.ln.D != 1024 || a.ln.x != a.out_f32 || a.ln.dw_w)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((gemm5_kernel<F16, EPI, RB, CB, WR, NST, ABL, LNE>), dim3(tiles_m * tiles_n), dim3(512), C::LDS, st, a, tiles_n, n_pad);
+    hipLaunchKernelGGL((gemm5_kernel<F16, EPI, RB, CB, WR, NST, ABL, LNE, WD>), dim3(tiles_m * tiles_n), dim3(512), lds, st, a, tiles_n, n_pad);
     return hipGetLastError();
 }
 
@@ -580,6 +707,14 @@ static hipError_t launch_gemm5(const GemmArgs& a, int rb, int cb, int n_pad, hip
         }
     }
 #endif
+    // W-direct (fragment-ordered weights present, K a multiple of 128): the wide tiles, in the 1 x 4 consumer layout (F5HIP_GEMM5_WD=0: off, A/B)
+    static const bool wd_on = !(getenv("F5HIP_GEMM5_WD") && atoi(getenv("F5HIP_GEMM5_WD")) == 0);
+    if (wd_on && a.Wf && a.K % 128 == 0 && cb >= 8) {
+        if (rb == 11 && cb == 8) return launch_gemm5_t<F16, EPI, 11, 8, 1, 6, 0, false, true>(a, n_pad, st);
+        if (rb == 11 && cb == 12) return launch_gemm5_t<F16, EPI, 11, 12, 1, 6, 0, false, true>(a, n_pad, st);
+        if (rb == 8 && cb == 8) return launch_gemm5_t<F16, EPI, 8, 8, 1, 6, 0, false, true>(a, n_pad, st);
+        if (rb == 8 && cb == 12) return launch_gemm5_t<F16, EPI, 8, 12, 1, 6, 0, false, true>(a, n_pad, st);
+    }
     if (rb == 11) {
         if (cb == 4) return launch_gemm5_t<F16, EPI, 11, 4, 4, 4>(a, n_pad, st);
         if (cb == 8) return launch_gemm5_t<F16, EPI, 11, 8, 2, 4>(a, n_pad, st);

@@ -34,6 +34,8 @@ struct GemmArgs {
     int lda;
     const __bf16* W[2];
     int ldw;              // row stride of W in elements (>= K)
+    const __bf16* Wf;     // W[0] once more in MFMA-fragment order (gemm5 W-direct kernels), or null: block (16 rows, 32 k) = 64 lanes x 8 elements,
+                          // lane = (row & 15) + 16 (k chunk of 8), offset ((row / 16) * (K / 32) + k / 32) * 512 elements
     int M, N, K;
     // implicit-GEMM conv (gemm.h only)
     int conv_kpt;         // k-tiles (of 32 channels) per tap

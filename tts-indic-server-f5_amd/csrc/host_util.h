@@ -37,6 +37,7 @@ struct Plane2 { __bf16* hi = nullptr; __bf16* lo = nullptr; };
 struct DevBuf { void* ptr = nullptr; };
 struct PackedW {
     __bf16* hi = nullptr; __bf16* lo = nullptr; float* bias = nullptr;
+    __bf16* frag = nullptr;   // f16 weights once more in MFMA-fragment order (pack_frag: the W-direct gemm5 kernels), or null
     int n = 0, k = 0, n_pad = 0, k_pad = 0, ld = 0;
     bool f16 = false;   // hi holds one fp16 plane, lo == nullptr
 };
@@ -100,6 +101,15 @@ static int pack_linear(PackedW& out, const float* w, int N, int K, int ldw, cons
     std::vector<float> b(out.n_pad, 0.0f);
     if (bias) std::copy(bias, bias + N, b.begin());
     return upload_f32(&out.bias, b.data(), b.size());
+}
+
+// fragment-ordered second copy of a one-plane fp16 weight (K a multiple of 128, rows a multiple of 16): GemmArgs::Wf
+static int pack_frag(PackedW& w, hipStream_t st = 0) {
+    if (!w.f16 || !w.hi || w.k_pad % 128 || w.ld != w.k_pad || w.n_pad % 16 || w.frag) return 0;
+    const size_t n = (size_t)w.n_pad * w.k_pad;
+    if (hipMalloc((void**)&w.frag, n * 2) != hipSuccess) { w.frag = nullptr; return fail(-4, "hipMalloc fragment-ordered weight %d x %d", w.n_pad, w.k_pad); }
+    hipLaunchKernelGGL(pack_frag_kernel, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, st, w.hi, w.n_pad, w.k_pad, w.ld, w.frag);
+    return hipGetLastError() == hipSuccess ? 0 : fail(-4, "pack_frag_kernel");
 }
 
 // ---------------------------------------------------------------- HIP-event profiling per kernel class

@@ -116,6 +116,8 @@ extern "C" int f5hip_op_gemm(int32_t M, int32_t N, int32_t K, const float* a_dev
         if (!W.hi || (!f16 && !W.lo)) return fail(-5, "op_gemm: hipMalloc weights");
         W.n = N; W.k = K; W.n_pad = N_pad; W.k_pad = K; W.ld = K; W.bias = bias; W.f16 = f16;
         op_pack_planes(w_dev, N, K, N_pad, W.hi, W.lo, f16, st);
+        if (f16 && N >= 2048 && pack_frag(W, st)) return -5;   // like the model's FF1 weights: fragment order for the W-direct kernels (freed with b)
+        if (W.frag) b.ptrs.push_back(W.frag);
     }
     op_pack_planes(a_dev, M, K, M_pad, A.hi, A.lo, f16, st);
     (void)hipMemsetAsync(bias, 0, sizeof(float) * N_pad, st);
@@ -205,6 +207,8 @@ extern "C" int f5hip_op_qkv(int32_t M, int32_t D, const float* a_dev, const floa
         hipMemcpyAsync(pos, hp.data(), hp.size() * 4, hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
         return fail(-6, "op_qkv: table upload");
     op_pack_planes(w_dev, N, D, N_pad, W.hi, W.lo, f16, st);
+    if (f16 && pack_frag(W, st)) return -5;
+    if (W.frag) b.ptrs.push_back(W.frag);
     op_pack_planes(a_dev, M, D, M_pad, A.hi, A.lo, f16, st);
     (void)hipMemsetAsync(bias, 0, sizeof(float) * N_pad, st);
     (void)hipMemcpyAsync(bias, bias_dev, sizeof(float) * N, hipMemcpyDeviceToDevice, st);
