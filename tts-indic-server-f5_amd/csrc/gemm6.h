@@ -264,6 +264,51 @@ F5_DEVICE void g6_direct_epilogue(const GemmArgs& p, f32x4 (&acc)[RBW][4], int m
 #undef G6_ACT
 }
 
+// Q / K tiles of the QKV projection straight from the accumulators: g5_qk_rows' arithmetic (bias, rotary on head 0 -- the first 64 columns
+// of the Q and of the K block: only the wc = 0 waves of the tiles at n0 = 0 and n0 = D -- the softmax scale on q, saturated fp16), per lane
+// 4 consecutive features of one token per (row block, column block).
+template <int RBW>
+F5_DEVICE void g6_qk_direct(const GemmArgs& p, f32x4 (&acc)[RBW][4], int n0, int m_w, int n_w, int n_blk, int m_end, int lane) {
+    const int fr = lane & 15, fq = lane >> 4;
+    const int D = p.D, which = n0 / D;                         // 0 = q, 1 = k (a tile is all one kind: D % 256 == 0)
+    const int ndw = n_w - which * D;                           // the wave's first column inside the q / k block
+    const bool rot = ndw == 0;                                 // head 0 (wave-uniform)
+    const float qs = which == 0 ? F5_Q_SCALE : 1.0f;
+    f32x4 bv[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) bv[j] = *reinterpret_cast<const f32x4*>(p.bias + n_w + j * 16 + fq * 4);
+#pragma unroll
+    for (int i = 0; i < RBW; i++) {
+        if (i >= n_blk) break;                                 // (wave-uniform)
+        const int row = m_w + i * 16 + fr;
+        const bool rok = row < m_end;
+        float2 cs[4], sn[4];
+        if (rot) {
+            const int pos = rok ? p.row_pos[row] : 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                cs[j] = *reinterpret_cast<const float2*>(p.rope_cos + pos * 32 + j * 8 + fq * 2);
+                sn[j] = *reinterpret_cast<const float2*>(p.rope_sin + pos * 32 + j * 8 + fq * 2);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const f32x4 v = acc[i][j] + bv[j];
+            float o[4];
+            if (rot) {
+                o[0] = __builtin_fmaf(v[0], cs[j].x, -__fmul_rn(v[1], sn[j].x)) * qs;
+                o[1] = __builtin_fmaf(v[1], cs[j].x, __fmul_rn(v[0], sn[j].x)) * qs;
+                o[2] = __builtin_fmaf(v[2], cs[j].y, -__fmul_rn(v[3], sn[j].y)) * qs;
+                o[3] = __builtin_fmaf(v[3], cs[j].y, __fmul_rn(v[2], sn[j].y)) * qs;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; e++) o[e] = v[e] * qs;
+            }
+            if (rok) store_f16x4(p.qk + (size_t)row * (2 * D) + which * D + ndw + j * 16 + fq * 4, o);
+        }
+    }
+}
+
 template <bool F16, int EPI, int RBW>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm6_kernel(const GemmArgs p, const int tiles_n, const int n_rows_w) {
     using C = Gemm6Cfg<RBW>;
@@ -282,11 +327,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // diagnostics (run time: p.stamps != null, tools/gemm6_stamps.py): s_memrealtime (100 MHz) of waves 0 and 4 of every workgroup at
     // [0] start, [1] k-loop done, [2..5] quarter s of the epilogue done, [6] stores drained
     unsigned long long* const stamp = (p.stamps && (tid == 0 || tid == 256)) ? p.stamps + ((size_t)blockIdx.x * 2 + (tid >> 8)) * 8 : nullptr;
-    if (stamp) stamp[0] = __builtin_amdgcn_s_memrealtime();
+    unsigned long long clk0 = 0;
+    if (stamp) { stamp[0] = __builtin_amdgcn_s_memrealtime(); clk0 = __builtin_amdgcn_s_memtime(); }
     f32x4 acc[RBW][4];
     if (swap) g6_kloop<F16, true, RBW>(p, smem, m0, n0, n_rows_w, wave, lane, acc);
     else g6_kloop<F16, false, RBW>(p, smem, m0, n0, n_rows_w, wave, lane, acc);
-    if (stamp) stamp[1] = __builtin_amdgcn_s_memrealtime();
+    if (stamp) { stamp[7] = __builtin_amdgcn_s_memtime() - clk0; stamp[1] = __builtin_amdgcn_s_memrealtime(); }   // [7]: shader cycles of the k-loop (the clock it ran at)
     // rows of the LDS image this tile owns: all of them, or 176 of the 192 (the last row block of the second wave group is the next tile's)
     const int m_end = min(p.M, m0 + C::BM);
     if constexpr (EPI == EPI_GENERIC) {
@@ -299,18 +345,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
         return;
     }
-    // QKV epilogue: four quarters of QR row blocks through one slab that aliases the dead ring; the row phases are gemm5's, which bound
-    // their stores by p.M: they see the tile's own end instead
+    if (swap) {   // Q / K tile: straight from the accumulators
+        const int n_blk = min(RBW, (C::BM - wr * RBW * 16) / 16);
+        g6_qk_direct<RBW>(p, acc, n0, m0 + wr * RBW * 16, n0 + wc * 64, n_blk, m_end, lane);
+        if (stamp) {
+            stamp[2] = stamp[3] = stamp[4] = stamp[5] = __builtin_amdgcn_s_memrealtime();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            stamp[6] = __builtin_amdgcn_s_memrealtime();
+        }
+        return;
+    }
+    // V tiles ([feature][token] output): four quarters of QR row blocks through one transposed slab that aliases the dead ring; the row phase
+    // is gemm5's, which bounds its stores by p.M: it sees the tile's own end instead
     GemmArgs pe = p;
     pe.M = m_end;
     float* slab = reinterpret_cast<float*>(smem);
-    auto write_rows = [&](auto half_t) {   // SWAP layout -> row-major slab [16 QR tokens][256 features]
-        constexpr int H = decltype(half_t)::value;
-#pragma unroll
-        for (int i = 0; i < QR; i++)
-#pragma unroll
-            for (int j = 0; j < 4; j++) *reinterpret_cast<f32x4*>(slab + (i * 16 + fr) * Q::SLD + wc * 64 + j * 16 + fq * 4) = acc[H * QR + i][j];
-    };
     auto write_cols = [&](auto half_t) {   // !SWAP layout -> transposed slab [256 features][16 QR tokens], + bias (V tiles)
         constexpr int H = decltype(half_t)::value;
 #pragma unroll
@@ -328,15 +377,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int mq = m0 + s * (QR * 16);
         if (mq >= m_end) break;                                     // (workgroup-uniform: quarters past the last row)
         const bool mine = wr == (s >> 1);
-        if (swap) {
-            if (mine) { if (s & 1) write_rows(I1{}); else write_rows(I0{}); }
-            __syncthreads();
-            g5_qk_rows<QR, 16, 3>(pe, slab, mq, n0, wave, lane);
-        } else {
-            if (mine) { if (s & 1) write_cols(I1{}); else write_cols(I0{}); }
-            __syncthreads();
-            g5_v_rows<QR, 16, 3>(pe, slab, mq, n0, 0, wave, lane);
-        }
+        if (mine) { if (s & 1) write_cols(I1{}); else write_cols(I0{}); }
+        __syncthreads();
+        g5_v_rows<QR, 16, 3>(pe, slab, mq, n0, 0, wave, lane);
         __syncthreads();                                            // the slab is free for the next quarter
         if (stamp) stamp[2 + s] = __builtin_amdgcn_s_memrealtime();
     }

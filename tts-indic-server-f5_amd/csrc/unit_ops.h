@@ -85,6 +85,17 @@ static int gemm6_stamp_report(OpBufs& b, int M, int N, int K, hipStream_t st, La
             std::sort(v.begin(), v.end());
             fprintf(stderr, "[gemm6 stamps]   wave %d  %-12s duration min %6.2f  median %6.2f  max %6.2f us\n", w * 4, names[i], v.front(), v[v.size() / 2], v.back());
         }
+    {   // the shader clock the k-loops ran at: s_memtime cycles over s_memrealtime (100 MHz) ticks
+        std::vector<double> v;
+        for (int g2 = 0; g2 < ng; g2++) {
+            const unsigned long long cyc = h[(size_t)g2 * 16 + 7], t0 = h[(size_t)g2 * 16], t1 = h[(size_t)g2 * 16 + 1];
+            if (cyc && t1 > t0) v.push_back((double)cyc / ((double)(t1 - t0) * 10.0));   // cycles per ns = GHz
+        }
+        if (!v.empty()) {
+            std::sort(v.begin(), v.end());
+            fprintf(stderr, "[gemm6 stamps]   shader clock during the k-loop: min %.2f  median %.2f  max %.2f GHz  (the 2.5 PFLOP/s roof is 2.4 GHz x 4096 FLOP / clk / CU x 256 CUs)\n", v.front(), v[v.size() / 2], v.back());
+        }
+    }
     {   // start times: how the rounds lay out
         std::vector<double> v;
         for (int g2 = 0; g2 < ng; g2++) v.push_back((h[(size_t)g2 * 16] - tmin) * 0.01);
