@@ -6,9 +6,15 @@
 
 #include "ln_row.h"
 
-template <int NV>
+// Row -> workgroup mapping, XCD-matched (XCD = 1; speed only, any bijection is correct): consecutive workgroup ids go round-robin to the 8 XCDs
+// and the block GEMMs give XCD x the row slabs of rows [x M / 8, (x + 1) M / 8) (gemm5_tile_of_block) -- both the GEMM that just wrote the
+// residual rows this kernel reads and the GEMM that reads the operand rows it writes.  With the same blocking here a row stays in one XCD's L2
+// from the residual epilogue through the norm to the next GEMM's first fill instead of crossing the fabric twice (F5HIP_LN_XCD=0: off, A/B).
+template <int NV, int XCD = 1>
 __global__ __launch_bounds__(256) void ln_kernel(const LnArgs p) {
-    ln_row<NV>(p, blockIdx.x * 4 + (threadIdx.x >> 6), threadIdx.x & 63);
+    unsigned b = blockIdx.x;
+    if (XCD && (gridDim.x & 7) == 0) b = (b & 7) * (gridDim.x >> 3) + (b >> 3);
+    ln_row<NV>(p, b * 4 + (threadIdx.x >> 6), threadIdx.x & 63);
 }
 
 // ------------------------------------------------------------------------------------------------

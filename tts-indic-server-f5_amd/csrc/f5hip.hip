@@ -599,11 +599,15 @@ static int run_ln(const LnArgs& a, hipStream_t st) {
     const int nv = (a.D + 255) / 256;
     dim3 grid((a.M + 3) / 4), blk(256);
     prof_begin(PROF_LN, st);
+    static const bool ln_xcd = !(getenv("F5HIP_LN_XCD") && atoi(getenv("F5HIP_LN_XCD")) == 0);
     switch (nv) {
         case 1: hipLaunchKernelGGL(ln_kernel<1>, grid, blk, 0, st, a); break;
         case 2: hipLaunchKernelGGL(ln_kernel<2>, grid, blk, 0, st, a); break;
         case 3: hipLaunchKernelGGL(ln_kernel<3>, grid, blk, 0, st, a); break;
-        case 4: hipLaunchKernelGGL(ln_kernel<4>, grid, blk, 0, st, a); break;
+        case 4:
+            if (ln_xcd) hipLaunchKernelGGL((ln_kernel<4, 1>), grid, blk, 0, st, a);
+            else hipLaunchKernelGGL((ln_kernel<4, 0>), grid, blk, 0, st, a);
+            break;
         case 5: case 6: hipLaunchKernelGGL(ln_kernel<6>, grid, blk, 0, st, a); break;
         default: return fail(-7, "ln: D=%d unsupported", a.D);
     }
