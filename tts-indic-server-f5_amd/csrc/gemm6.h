@@ -53,8 +53,70 @@ struct Gemm6Cfg {
 };
 
 // one K-loop; SWAP as in gemm5 (true: the W fragment is the MFMA's A operand, a lane holds 4 consecutive FEATURES of a token)
+// One 1 KiB LDS-DMA piece with a wave-uniform 64-bit base (SGPR pair) and a 32-bit per-lane byte offset: the eight source addresses of a
+// wave then cost 8 VGPRs instead of 16 (the 256-row kernels sit at the register limit).  M0 handling as attn_lds_dma16 (attn_common.h).
+F5_DEVICE unsigned g6_lds_addr(const char* smem) { return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)smem; }   // (once per kernel: a generic -> LDS cast carries a null check)
+F5_DEVICE void g6_dma16(const void* base, unsigned off, unsigned lds_dst) {
+    const unsigned d = __builtin_amdgcn_readfirstlane(lds_dst);
+    const unsigned long long b = (unsigned long long)base;
+    const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)b), bhi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+    const unsigned long long bs = ((unsigned long long)bhi << 32) | blo;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(off), "s"(bs), "s"(d) : "memory");
+}
+
+// DMA sources of a tile: half-tile h (0 A-lo, 1 A-hi, 2 W-lo, 3 W-hi), piece pp (0 / 1) = rows (wave + 8 pp) * 8 + (lane >> 3) of the half-tile.
+// Rows past the matrices (a partial last slab) re-read the last valid row: finite data, never stored.
+template <int RBW>
+F5_DEVICE void g6_sources(const GemmArgs& p, int m0, int n0, int n_rows_w, int wave, int lane, unsigned (&src)[4][2]) {
+#pragma unroll
+    for (int h = 0; h < 4; h++)
+#pragma unroll
+        for (int pp = 0; pp < 2; pp++) {
+            const int row = (wave + 8 * pp) * 8 + (lane >> 3);
+            const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+            const bool isA = h < 2;
+            const int grow = isA ? min(m0 + (h & 1) * (RBW * 16) + row, p.M - 1) : min(n0 + (h & 1) * 128 + row, n_rows_w - 1);
+            src[h][pp] = ((unsigned)grow * (unsigned)(isA ? p.lda : p.ldw) + (unsigned)chunk * 8u) * 2u;   // byte offset from A[0] / W[0] (< 4 GiB: checked at launch)
+        }
+}
+template <int RBW>
+F5_DEVICE void g6_stage(const GemmArgs& p, const unsigned (&src)[4][2], unsigned lds0, int wave, int h, int kt) {   // half-tile h of K-tile kt -> buffer kt & 1
+    using C = Gemm6Cfg<RBW>;
+    const unsigned dst = lds0 + (kt & 1) * C::BUF + (h < 2 ? h * C::AH : 2 * C::AH + (h - 2) * C::WH) + wave * 1024;
+    const void* base = h < 2 ? (const void*)p.A[0] : (const void*)p.W[0];
+    g6_dma16(base, src[h][0] + (unsigned)kt * 128u, dst);
+    if (C::APIECES == 16 || h >= 2 || wave < C::APIECES - 8) g6_dma16(base, src[h][1] + (unsigned)kt * 128u, dst + 8192);   // (an A half-tile has 16 or 12 pieces)
+}
+// prologue of a tile: K-tile 0 and the W halves of K-tile 1 (the persistent kernel issues it for the NEXT tile before the epilogue of the
+// current one, so the first K-tiles land while the accumulators are being written out)
+template <int RBW>
+F5_DEVICE void g6_prologue(const GemmArgs& p, unsigned lds0, int m0, int n0, int n_rows_w, int wave, int lane) {
+    using C = Gemm6Cfg<RBW>;
+    const bool two = (p.K >> 6) > 1;
+    // (one source pointer alive at a time: the accumulators of the tile being finished own the registers)
+#pragma unroll
+    for (int h = 0; h < 4; h++)
+#pragma unroll
+        for (int pp = 0; pp < 2; pp++) {
+            if (C::APIECES < 16 && h < 2 && pp == 1 && wave >= C::APIECES - 8) continue;   // (an A half-tile has 16 or 12 pieces; wave-uniform)
+            const int row = (wave + 8 * pp) * 8 + (lane >> 3);
+            const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+            const bool isA = h < 2;
+            const int grow = isA ? min(m0 + (h & 1) * (RBW * 16) + row, p.M - 1) : min(n0 + (h & 1) * 128 + row, n_rows_w - 1);
+            const unsigned off = ((unsigned)grow * (unsigned)(isA ? p.lda : p.ldw) + (unsigned)chunk * 8u) * 2u;
+            const void* base = isA ? (const void*)p.A[0] : (const void*)p.W[0];
+            const unsigned dst = lds0 + (h < 2 ? h * C::AH : 2 * C::AH + (h - 2) * C::WH) + wave * 1024 + pp * 8192;
+            g6_dma16(base, off, dst);                                   // K-tile 0 -> buffer 0
+            if (!isA && two) g6_dma16(base, off + 128u, dst + C::BUF);  // the W halves of K-tile 1 -> buffer 1
+            asm volatile("" ::: "memory");
+        }
+}
+
+// STAGED: the prologue of this tile was issued earlier (g6_prologue, with other vector-memory traffic behind it: wait for everything)
 template <bool F16, bool SWAP, int RBW>
-F5_DEVICE void g6_kloop(const GemmArgs& p, char* smem, int m0, int n0, int n_rows_w, int wave, int lane, f32x4 (&acc)[RBW][4]) {
+F5_DEVICE void g6_kloop(const GemmArgs& p, char* smem, unsigned lds0, int m0, int n0, int n_rows_w, int wave, int lane, f32x4 (&acc)[RBW][4], bool staged) {
     using C = Gemm6Cfg<RBW>;
     constexpr int AH = C::AH, WH = C::WH, BUF = C::BUF, QR = C::QR;
     const int wr = wave >> 2, wc = wave & 3;
@@ -66,27 +128,9 @@ F5_DEVICE void g6_kloop(const GemmArgs& p, char* smem, int m0, int n0, int n_row
 #pragma unroll
         for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // DMA sources: half-tile h (0 A-lo, 1 A-hi, 2 W-lo, 3 W-hi), piece pp (0 / 1) = rows (wave + 8 pp) * 8 + (lane >> 3) of the half-tile.
-    // Rows past the matrices (a partial last slab) re-read the last valid row: finite data, never stored.
-    // An A half-tile has C::APIECES pieces (16 or 12): every wave moves piece `wave`, and piece `wave + 8` if there is one.
-    const bool a_second = wave + 8 < C::APIECES;   // (wave-uniform)
-    const char* src[4][2];
-#pragma unroll
-    for (int h = 0; h < 4; h++)
-#pragma unroll
-        for (int pp = 0; pp < 2; pp++) {
-            const int row = (wave + 8 * pp) * 8 + (lane >> 3);
-            const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-            const bool isA = h < 2;
-            const int grow = isA ? min(m0 + (h & 1) * (RBW * 16) + row, p.M - 1) : min(n0 + (h & 1) * 128 + row, n_rows_w - 1);
-            const __bf16* base = isA ? p.A[0] + (size_t)grow * p.lda : p.W[0] + (size_t)grow * p.ldw;
-            src[h][pp] = reinterpret_cast<const char*>(base + chunk * 8);
-        }
-    auto stage = [&](int h, int kt) {   // half-tile h of K-tile kt -> buffer kt & 1
-        char* dst = smem + (kt & 1) * BUF + (h < 2 ? h * AH : 2 * AH + (h - 2) * WH) + wave * 1024;
-        attn_lds_dma16(src[h][0] + (size_t)kt * 128, dst);
-        if (h >= 2 || a_second) attn_lds_dma16(src[h][1] + (size_t)kt * 128, dst + 8192);
-    };
+    unsigned src[4][2];
+    g6_sources<RBW>(p, m0, n0, n_rows_w, wave, lane, src);
+    auto stage = [&](int h, int kt) { g6_stage<RBW>(p, src, lds0, wave, h, kt); };
     bf16x8 fa[2 * QR], fb[2][4];   // fa[kh * QR + i]: row block i of the current row half; fb[qn][kh * 2 + j]
     auto read_a = [&](int kt, int qm) {
         const char* b = smem + (kt & 1) * BUF + wr * AH + qm * (QR * 2048);
@@ -147,8 +191,12 @@ F5_DEVICE void g6_kloop(const GemmArgs& p, char* smem, int m0, int n0, int n_row
         mfma_quadrant(I1{}, I0{});
     };
     // prologue: K-tile 0 and the W halves of K-tile 1
-    stage(0, 0); stage(1, 0); stage(2, 0); stage(3, 0);
-    if (nk > 1) { stage(2, 1); stage(3, 1); attn_wait_vmcnt<4>(); } else attn_wait_vmcnt<0>();
+    if (staged) {
+        attn_wait_vmcnt<0>();
+    } else {
+        stage(0, 0); stage(1, 0); stage(2, 0); stage(3, 0);
+        if (nk > 1) { stage(2, 1); stage(3, 1); attn_wait_vmcnt<4>(); } else attn_wait_vmcnt<0>();
+    }
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     if (wr == 1) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }   // the later group: half a phase behind from here on
@@ -309,93 +357,109 @@ F5_DEVICE void g6_qk_direct(const GemmArgs& p, f32x4 (&acc)[RBW][4], int n0, int
     }
 }
 
+// PERSISTENT grid: workgroup b works through tiles b, b + gridDim.x, ... (the grid is one workgroup per CU, or the tile count if smaller).
+// When the next tile's epilogue-free start is known -- the current tile writes its results straight from the accumulators (generic and Q / K
+// tiles; V tiles need the LDS for their transposed slab) -- the NEXT tile's prologue (K-tile 0 + the W halves of K-tile 1: 12 LDS-DMA pieces
+// per wave) is issued BEFORE the current epilogue: the ring is dead, the accumulators are in registers, and the ~2 us the first K-tile takes
+// to land from beyond L2 pass behind 5-10 us of epilogue instead of in front of the next k-loop.
 template <bool F16, int EPI, int RBW>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm6_kernel(const GemmArgs p, const int tiles_n, const int n_rows_w) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm6_kernel(const GemmArgs p, const int tiles_n, const int n_rows_w, const int n_tiles) {
     using C = Gemm6Cfg<RBW>;
     using Q = typename C::Q;
     constexpr int QR = C::QR;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tile = gemm5_tile_of_block(blockIdx.x, gridDim.x);
-    const int m0 = (tile / tiles_n) * C::BM, n0 = (tile % tiles_n) * C::BN;
     const int wr = wave >> 2, wc = wave & 3;
     const int fr = lane & 15, fq = lane >> 4;
-    // all-V tiles of the QKV projection keep the token on the accumulator registers (their output is [feature][token]); D % 256 == 0, so a
-    // tile is all Q, all K or all V
-    const bool swap = !(EPI == EPI_QKV && n0 >= 2 * p.D);
-    // diagnostics (run time: p.stamps != null, tools/gemm6_stamps.py): s_memrealtime (100 MHz) of waves 0 and 4 of every workgroup at
-    // [0] start, [1] k-loop done, [2..5] quarter s of the epilogue done, [6] stores drained
-    unsigned long long* const stamp = (p.stamps && (tid == 0 || tid == 256)) ? p.stamps + ((size_t)blockIdx.x * 2 + (tid >> 8)) * 8 : nullptr;
-    unsigned long long clk0 = 0;
-    if (stamp) { stamp[0] = __builtin_amdgcn_s_memrealtime(); clk0 = __builtin_amdgcn_s_memtime(); }
-    f32x4 acc[RBW][4];
-    if (swap) g6_kloop<F16, true, RBW>(p, smem, m0, n0, n_rows_w, wave, lane, acc);
-    else g6_kloop<F16, false, RBW>(p, smem, m0, n0, n_rows_w, wave, lane, acc);
-    if (stamp) { stamp[7] = __builtin_amdgcn_s_memtime() - clk0; stamp[1] = __builtin_amdgcn_s_memrealtime(); }   // [7]: shader cycles of the k-loop (the clock it ran at)
-    // rows of the LDS image this tile owns: all of them, or 176 of the 192 (the last row block of the second wave group is the next tile's)
-    const int m_end = min(p.M, m0 + C::BM);
-    if constexpr (EPI == EPI_GENERIC) {
+    const unsigned lds0 = g6_lds_addr(smem);
+    // diagnostics (run time: p.stamps != null, tools/gemm6_stamps.py): s_memrealtime (100 MHz) of waves 0 and 4 at [0] start, [1] k-loop done,
+    // [2..5] epilogue done (quarter s of a V tile), [6] stores drained, [7] shader cycles of the k-loop -- of the workgroup's FIRST tile
+    // (kept as a wave-uniform flag and re-derived at every use: a per-lane pointer alive across the k-loop costs the 256-row kernels registers
+    // they do not have)
+    bool stamping = p.stamps != nullptr;
+#define G6_STAMP_PTR() (p.stamps + ((size_t)blockIdx.x * 2 + (tid >> 8)) * 8)
+#define G6_STAMP(EXPR) if (stamping && (tid == 0 || tid == 256)) { unsigned long long* stamp = G6_STAMP_PTR(); EXPR; }
+    bool staged = false;
+    for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const int tile = gemm5_tile_of_block(t, n_tiles);
+        const int m0 = (tile / tiles_n) * C::BM, n0 = (tile % tiles_n) * C::BN;
+        // all-V tiles of the QKV projection keep the token on the accumulator registers (their output is [feature][token]); D % 256 == 0, so a
+        // tile is all Q, all K or all V
+        const bool swap = !(EPI == EPI_QKV && n0 >= 2 * p.D);
+        G6_STAMP(stamp[0] = __builtin_amdgcn_s_memrealtime(); stamp[7] = __builtin_amdgcn_s_memtime())
+        f32x4 acc[RBW][4];
+        if (swap) g6_kloop<F16, true, RBW>(p, smem, lds0, m0, n0, n_rows_w, wave, lane, acc, staged);
+        else g6_kloop<F16, false, RBW>(p, smem, lds0, m0, n0, n_rows_w, wave, lane, acc, staged);
+        G6_STAMP(stamp[7] = __builtin_amdgcn_s_memtime() - stamp[7]; stamp[1] = __builtin_amdgcn_s_memrealtime())
+        // the next tile's first K-tiles, if this tile's epilogue leaves the LDS alone
+        staged = false;
+        if (swap && t + (int)gridDim.x < n_tiles) {                 // (workgroup-uniform)
+            const int tn = gemm5_tile_of_block(t + gridDim.x, n_tiles);
+            g6_prologue<RBW>(p, lds0, (tn / tiles_n) * C::BM, (tn % tiles_n) * C::BN, n_rows_w, wave, lane);
+            staged = true;
+        }
+        // rows of the LDS image this tile owns: all of them, or 176 of the 192 (the last row block of the second wave group is the next tile's)
+        const int m_end = min(p.M, m0 + C::BM);
         const int n_blk = min(RBW, (C::BM - wr * RBW * 16) / 16);
-        g6_direct_epilogue<RBW>(p, acc, m0, n0, m0 + wr * RBW * 16, n0 + wc * 64, n_blk, lane);
-        if (stamp) {
-            stamp[2] = stamp[3] = stamp[4] = stamp[5] = __builtin_amdgcn_s_memrealtime();
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            stamp[6] = __builtin_amdgcn_s_memrealtime();
-        }
-        return;
-    }
-    if (swap) {   // Q / K tile: straight from the accumulators
-        const int n_blk = min(RBW, (C::BM - wr * RBW * 16) / 16);
-        g6_qk_direct<RBW>(p, acc, n0, m0 + wr * RBW * 16, n0 + wc * 64, n_blk, m_end, lane);
-        if (stamp) {
-            stamp[2] = stamp[3] = stamp[4] = stamp[5] = __builtin_amdgcn_s_memrealtime();
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            stamp[6] = __builtin_amdgcn_s_memrealtime();
-        }
-        return;
-    }
-    // V tiles ([feature][token] output): four quarters of QR row blocks through one transposed slab that aliases the dead ring; the row phase
-    // is gemm5's, which bounds its stores by p.M: it sees the tile's own end instead
-    GemmArgs pe = p;
-    pe.M = m_end;
-    float* slab = reinterpret_cast<float*>(smem);
-    auto write_cols = [&](auto half_t) {   // !SWAP layout -> transposed slab [256 features][16 QR tokens], + bias (V tiles)
-        constexpr int H = decltype(half_t)::value;
+        if (EPI == EPI_GENERIC || swap) {
+            if constexpr (EPI == EPI_GENERIC) g6_direct_epilogue<RBW>(p, acc, m0, n0, m0 + wr * RBW * 16, n0 + wc * 64, n_blk, lane);
+            else g6_qk_direct<RBW>(p, acc, n0, m0 + wr * RBW * 16, n0 + wc * 64, n_blk, m_end, lane);   // Q / K tile
+            G6_STAMP(stamp[2] = stamp[3] = stamp[4] = stamp[5] = __builtin_amdgcn_s_memrealtime())
+        } else {
+            // V tiles ([feature][token] output): four quarters of QR row blocks through one transposed slab that aliases the dead ring; the row
+            // phase is gemm5's, which bounds its stores by p.M: it sees the tile's own end instead
+            GemmArgs pe = p;
+            pe.M = m_end;
+            float* slab = reinterpret_cast<float*>(smem);
+            auto write_cols = [&](auto half_t) {   // !SWAP layout -> transposed slab [256 features][16 QR tokens], + bias
+                constexpr int H = decltype(half_t)::value;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const float b1 = p.bias[n0 + wc * 64 + j * 16 + fr];
+                for (int j = 0; j < 4; j++) {
+                    const float b1 = p.bias[n0 + wc * 64 + j * 16 + fr];
 #pragma unroll
-            for (int i = 0; i < QR; i++)
-                *reinterpret_cast<f32x4*>(slab + (wc * 64 + j * 16 + fr) * Q::SLDT + i * 16 + fq * 4) = acc[H * QR + i][j] + (f32x4){b1, b1, b1, b1};
-        }
-    };
-    using I0 = std::integral_constant<int, 0>;
-    using I1 = std::integral_constant<int, 1>;
+                    for (int i = 0; i < QR; i++)
+                        *reinterpret_cast<f32x4*>(slab + (wc * 64 + j * 16 + fr) * Q::SLDT + i * 16 + fq * 4) = acc[H * QR + i][j] + (f32x4){b1, b1, b1, b1};
+                }
+            };
+            using I0 = std::integral_constant<int, 0>;
+            using I1 = std::integral_constant<int, 1>;
 #pragma unroll 1
-    for (int s = 0; s < 4; s++) {
-        const int mq = m0 + s * (QR * 16);
-        if (mq >= m_end) break;                                     // (workgroup-uniform: quarters past the last row)
-        const bool mine = wr == (s >> 1);
-        if (mine) { if (s & 1) write_cols(I1{}); else write_cols(I0{}); }
-        __syncthreads();
-        g5_v_rows<QR, 16, 3>(pe, slab, mq, n0, 0, wave, lane);
-        __syncthreads();                                            // the slab is free for the next quarter
-        if (stamp) stamp[2 + s] = __builtin_amdgcn_s_memrealtime();
+            for (int s4 = 0; s4 < 4; s4++) {
+                const int mq = m0 + s4 * (QR * 16);
+                if (mq >= m_end) break;                             // (workgroup-uniform: quarters past the last row)
+                const bool mine = wr == (s4 >> 1);
+                if (mine) { if (s4 & 1) write_cols(I1{}); else write_cols(I0{}); }
+                __syncthreads();
+                g5_v_rows<QR, 16, 3>(pe, slab, mq, n0, 0, wave, lane);
+                __syncthreads();                                    // the slab is free for the next quarter (and, after the last one, for the ring)
+                G6_STAMP(stamp[2 + s4] = __builtin_amdgcn_s_memrealtime())
+            }
+        }
+        if (stamping) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            G6_STAMP(stamp[6] = __builtin_amdgcn_s_memrealtime())
+            stamping = false;                                       // (first tile only)
+        }
     }
-    if (stamp) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        stamp[6] = __builtin_amdgcn_s_memrealtime();
-    }
+#undef G6_STAMP
+#undef G6_STAMP_PTR
 }
 
 template <bool F16, int EPI, int RBW>
 static hipError_t launch_gemm6_t(const GemmArgs& a, int n_pad, hipStream_t st) {
     using C = Gemm6Cfg<RBW>;
     if (n_pad % C::BN || a.K % 64 || a.K < 64 || (EPI == EPI_QKV && a.D % C::BN)) return hipErrorInvalidValue;
+    if ((unsigned long long)a.M * a.lda * 2ull >= (1ull << 32) || (unsigned long long)n_pad * a.ldw * 2ull >= (1ull << 32)) return hipErrorInvalidValue;   // 32-bit DMA offsets
     static unsigned attr_mask = 0;
     if (hipError_t e = f5_set_lds_attr(reinterpret_cast<const void*>(&gemm6_kernel<F16, EPI, RBW>), C::LDS, attr_mask); e != hipSuccess) return e;
-    const int tiles_m = (a.M + C::BM - 1) / C::BM, tiles_n = n_pad / C::BN;
-    hipLaunchKernelGGL((gemm6_kernel<F16, EPI, RBW>), dim3(tiles_m * tiles_n), dim3(512), C::LDS, st, a, tiles_n, n_pad);
+    const int tiles_m = (a.M + C::BM - 1) / C::BM, tiles_n = n_pad / C::BN, n_tiles = tiles_m * tiles_n;
+    static int n_cu = 0;                                            // persistent grid: one workgroup per CU (F5HIP_GEMM6_PERSIST=0: one per tile, A/B)
+    if (!n_cu) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        n_cu = (getenv("F5HIP_GEMM6_PERSIST") && atoi(getenv("F5HIP_GEMM6_PERSIST")) == 0) ? (1 << 30) : cus;
+    }
+    hipLaunchKernelGGL((gemm6_kernel<F16, EPI, RBW>), dim3(n_tiles < n_cu ? n_tiles : n_cu), dim3(512), C::LDS, st, a, tiles_n, n_pad, n_tiles);
     return hipGetLastError();
 }
