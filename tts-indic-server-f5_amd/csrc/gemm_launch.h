@@ -32,6 +32,7 @@ hipError_t f5_launch_conv5(int prec, const GemmArgs& a, int n_pad, hipStream_t s
 // attn3.h: flash attention forward, 256 queries per workgroup
 hipError_t f5_launch_attn3(const AttnArgs& a, int max_len, int heads, int n_seq, hipStream_t st);
 void f5_set_attn_shape_invariant(int on);
+hipError_t f5_launch_attn5(const AttnArgs& a, int max_len, int heads, int n_seq, hipStream_t st);   // attn5.h: ping-pong kernel (single key range)
 // experiments/attn4.h (unequal-height waves, 16 x 16 x 32 MFMA; attn3 unless built with -DF5HIP_EXPERIMENTS)
 hipError_t f5_launch_attn4(const AttnArgs& a, int max_len, int heads, int n_seq, hipStream_t st);
 

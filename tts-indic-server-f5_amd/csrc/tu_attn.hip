@@ -3,6 +3,7 @@
 #include "attn3.h"
 #ifdef F5HIP_EXPERIMENTS
 #include "experiments/attn4.h"
+#include "experiments/attn5.h"
 #endif
 #include "gemm_launch.h"
 
@@ -31,8 +32,25 @@ static void attn3_launch(const AttnArgs& a, int best, bool deep, bool bal, dim3 
     else hipLaunchKernelGGL((attn3_fwd_kernel<4, SEG2, false, 5>), grid, dim3(256), 0, st, a);
 }
 
+// attn5 (experiments/attn5.h, -DF5HIP_EXPERIMENTS builds only): the ping-pong kernel, 256 queries per workgroup, single key range.  Measured
+// 11-40 % slower than attn3 (profiles/r03_attn5_pingpong.txt); without the experiments flag this is attn3.
+hipError_t f5_launch_attn3(const AttnArgs& a, int max_len, int heads, int n_seq, hipStream_t st);
+hipError_t f5_launch_attn5(const AttnArgs& a, int max_len, int heads, int n_seq, hipStream_t st) {
+#ifdef F5HIP_EXPERIMENTS
+    if (a.seq_kv2_row0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((attn5_fwd_kernel<6>), dim3((max_len + 255) / 256, heads, n_seq), dim3(512), 0, st, a);
+    return hipGetLastError();
+#else
+    return f5_launch_attn3(a, max_len, heads, n_seq, st);
+#endif
+}
+
 hipError_t f5_launch_attn3(const AttnArgs& a, int max_len, int heads, int n_seq, hipStream_t st) {
     if (a.seq_kv2_row0 && (!a.seq_kv_row0 || !a.seq_kv2_len)) return hipErrorInvalidValue;   // two key ranges per (pseudo-)sequence: MMDiT joint attention
+#ifdef F5HIP_EXPERIMENTS
+    static const int use5 = getenv("F5HIP_ATTN5") ? atoi(getenv("F5HIP_ATTN5")) : 0;
+    if (use5 && !a.seq_kv2_row0) return f5_launch_attn5(a, max_len, heads, n_seq, st);
+#endif
     bool no_bal = false;
 #ifdef F5HIP_EXPERIMENTS
     static const int force_qb = getenv("F5HIP_ATTN_QB") ? atoi(getenv("F5HIP_ATTN_QB")) : 0;

@@ -281,7 +281,7 @@ __global__ __launch_bounds__(256) void op_unpack_planes_kernel(const __bf16* hi,
 // impl 3 = attn3 (production), 4 = experiments/attn4.h (attn3 unless built with -DF5HIP_EXPERIMENTS).
 extern "C" int f5hip_op_attention(int32_t n_seq, const int32_t* seq_len, const int32_t* kv_len, int32_t heads, const float* q_dev,
                                   const float* k_dev, const float* v_dev, float* out_dev, int32_t impl, int32_t iters, double* avg_us, void* stream) {
-    if (n_seq <= 0 || !seq_len || heads <= 0 || !q_dev || !k_dev || !v_dev || !out_dev || (impl != 3 && impl != 4)) return fail(-1, "op_attention: bad argument");
+    if (n_seq <= 0 || !seq_len || heads <= 0 || !q_dev || !k_dev || !v_dev || !out_dev || (impl != 3 && impl != 4 && impl != 5)) return fail(-1, "op_attention: bad argument");
     hipStream_t st = (hipStream_t)stream;
     const int D = heads * 64;
     int M_pad = 0, F = 0, max_len = 0;
@@ -314,7 +314,7 @@ extern "C" int f5hip_op_attention(int32_t n_seq, const int32_t* seq_len, const i
     hipError_t e = hipSuccess;
     for (int it = -1; it < iters && e == hipSuccess; it++) {
         if (it == 0) (void)hipEventRecord(e0, st);
-        e = impl == 3 ? f5_launch_attn3(at, max_len, heads, n_seq, st) : f5_launch_attn4(at, max_len, heads, n_seq, st);
+        e = impl == 3 ? f5_launch_attn3(at, max_len, heads, n_seq, st) : impl == 5 ? f5_launch_attn5(at, max_len, heads, n_seq, st) : f5_launch_attn4(at, max_len, heads, n_seq, st);
     }
     (void)hipEventRecord(e1, st);
     (void)hipEventSynchronize(e1);
