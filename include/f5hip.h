@@ -141,20 +141,21 @@ int f5hip_op_gemm(int32_t M, int32_t N, int32_t K, const float* a_dev, const flo
                   uint16_t* out16_dev, int32_t w_copies, int32_t iters, double* avg_us, void* stream);
 /* f5hip_op_qkv: fused to_q | to_k | to_v projection with its epilogue: bias, rotary embedding on channels 0..63 (head 0, interleaved
  *   pairs) of q and k, q * log2(e) / 8 (the attention kernel's scores are base-2 exponents), V transposed (F/model/modules.py:409-426).  a_dev [M][D], w_dev [3 D][D], bias_dev [3 D], row_pos host
- *   int32 [M] (rotary position of every row, 0..4096); outputs bf16: qk_dev [ceil128(M)][2 D], vt_dev [D][ceil128(M)] with the tokens of
+ *   int32 [M] (rotary position of every row, 0..4096); outputs fp16 (saturated): qk_dev [ceil128(M)][2 D], vt_dev [D][ceil128(M)] with the tokens of
  *   every aligned group of 16 in the order 0-3, 8-11, 4-7, 12-15 (the order the attention kernel's PV fragments read them in). */
 int f5hip_op_qkv(int32_t M, int32_t D, const float* a_dev, const float* w_dev, const float* bias_dev, const int32_t* row_pos,
                  int32_t prec, uint16_t* qk_dev, uint16_t* vt_dev, int32_t iters, double* avg_us, void* stream);
 /* f5hip_op_attention: softmax(q k^T / 8 + key-padding mask) v per (sequence, head), head dim 64 -- F.scaled_dot_product_attention with the
  *   reference's [b, 1, 1, n] key mask (F/model/modules.py:424-436).  q_dev / k_dev / v_dev / out_dev fp32 [sum(seq_len)][64 heads], sequences
- *   packed back to back; kv_len[i] <= seq_len[i] valid keys (NULL: all).  Operands are rounded to bf16 like the QKV epilogue's outputs.
- *   impl 3 = the production kernel (attn3); 4 = the experimental unequal-wave kernel (attn3 unless the library was built with experiments). */
+ *   packed back to back; kv_len[i] <= seq_len[i] valid keys (NULL: all).  Operands are rounded to fp16 (saturated) like the QKV epilogue's outputs.
+ *   impl 3 = the production kernel (attn3); 4 / 5 = the experimental unequal-wave / ping-pong kernels (attn3 unless the library was built
+ *   with experiments). */
 int f5hip_op_attention(int32_t n_seq, const int32_t* seq_len, const int32_t* kv_len, int32_t heads, const float* q_dev, const float* k_dev,
                        const float* v_dev, float* out_dev, int32_t impl, int32_t iters, double* avg_us, void* stream);
 /* f5hip_op_joint_attention: the joint attention of the MMDiT blocks (JointAttnProcessor, F/model/modules.py:496-522): per sequence the
  *   queries and the keys are its audio rows followed by its text rows; only audio keys can be padding (x_kvlen[i] <= x_len[i] valid; NULL:
  *   all).  q_dev / k_dev / v_dev / out_dev fp32 [sum(x_len) + sum(c_len)][64 heads]: all audio frames sequence by sequence, then all
- *   text tokens sequence by sequence.  Operands are rounded to bf16 like the QKV epilogue's outputs. */
+ *   text tokens sequence by sequence.  Operands are rounded to fp16 (saturated) like the QKV epilogue's outputs. */
 int f5hip_op_joint_attention(int32_t n_seq, const int32_t* x_len, const int32_t* x_kvlen, const int32_t* c_len, int32_t heads,
                              const float* q_dev, const float* k_dev, const float* v_dev, float* out_dev, void* stream);
 /* f5hip_op_layernorm: y = LN(x) * (gain_off + scale) + shift (AdaLN: gain_off 1; affine LN: gain_off 0; F/model/modules.py:285-290),
