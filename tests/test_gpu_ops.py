@@ -169,6 +169,32 @@ def test_qkv_unit_op(M, D, prec):
         assert _rel(got, ref.double()) < 4e-4, name
 
 
+def test_qkv_and_attention_operands_saturate():
+    """The attention operands are fp16 since round 3 (csrc/attn3.h): a q / k / v value beyond the fp16 range must leave the QKV epilogue as +-65504,
+    never as inf (an inf score would make exp2 produce NaN through inf - inf in the next block), and the attention kernel must stay finite on
+    operands at that limit (the fixed-offset fast loop overflows its fp16 probabilities there and the workgroup redoes its tile)."""
+    from tts_indic_server_f5_amd import ops
+    g = torch.Generator().manual_seed(77)
+    M, D = 300, 256
+    a = torch.randn(M, D, generator=g)
+    w = torch.randn(3 * D, D, generator=g) / D ** 0.5
+    a[7] *= 3.0e5                                   # row 7: |q|, |k|, |v| far beyond 65504
+    gq, gk, gv, _ = ops.qkv(a.to(DEV), w.to(DEV), torch.zeros(3 * D), torch.arange(M).numpy(), prec=2)
+    for t in (gq, gk, gv):
+        assert torch.isfinite(t).all() and t[7].abs().max().item() == 65504.0
+    n, heads = 200, 2
+    q = torch.randn(n, 64 * heads, generator=g)
+    k = torch.randn(n, 64 * heads, generator=g)
+    v = torch.randn(n, 64 * heads, generator=g)
+    k[150] = 60000.0                                # one key at the fp16 limit: scores of +-1e5 for every query
+    out, _ = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), (n,), None, heads=heads)
+    assert torch.isfinite(out).all()
+    qs = (q * Q_SCALE).half().double().view(n, heads, 64).transpose(0, 1) * math.log(2.0)
+    ks, vs = (t.half().double().view(n, heads, 64).transpose(0, 1) for t in (k, v))
+    ref = (torch.softmax(qs @ ks.transpose(1, 2), dim=-1) @ vs).transpose(0, 1).reshape(n, 64 * heads)
+    assert (out.double().cpu() - ref).abs().max().item() < 2.5e-3
+
+
 @pytest.mark.parametrize("rms", [False, True])
 def test_layernorm_unit_op(rms):
     from tts_indic_server_f5_amd import ops
