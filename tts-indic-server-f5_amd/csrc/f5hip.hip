@@ -41,6 +41,7 @@ struct f5hip_dit {
     // per-handle settings (the process-wide setters are only their defaults)
     int attn_invariant = -1;          // f5hip_dit_set_attention_shape_invariant: -1 = follow f5hip_set_attention_shape_invariant
     ProfState* prof = nullptr;        // f5hip_dit_set_profiling: this handle's own HIP-event spans and totals (null: the process-wide state)
+    HostStage up_meta, up_time[2];    // pinned staging of the per-call uploads (row metadata; the two planes of the sinusoid table)
     bool blk_f16 = false; // gemm_planes == 3: transformer-block GEMMs (QKV, out, FF1, FF2) take one fp16 plane per operand
     bool skip_f16 = false; // UNetT (experiment, F5HIP_UNETT_SKIP_F16=1): the U-skip projections too
     // LayerNorm fused behind the residual GEMMs (gemm5 LNE kernels: experiments builds only, measured slower): per-handle arrival
@@ -155,6 +156,7 @@ void f5hip_dit_destroy(f5hip_dit* m) {
 #endif
     dev_free(m->meta);
     delete m->prof;
+    m->up_meta.release(); m->up_time[0].release(); m->up_time[1].release();
     delete m;
 }
 
@@ -486,9 +488,7 @@ static int setup_sequences(f5hip_dit* m, const std::vector<SeqDesc>& seqs, int n
             rc0 += ceil_to(q.c_len, 128);
         }
     }
-    if (hipMemcpyAsync(m->meta, hbuf.data(), sizeof(int) * hbuf.size(), hipMemcpyHostToDevice, st) != hipSuccess)
-        return fail(-6, "metadata upload");
-    if (hipStreamSynchronize(st) != hipSuccess) return fail(-6, "metadata upload sync");   // hbuf is a stack-scoped host buffer
+    if (const int r_ = m->up_meta.upload(m->meta, hbuf.data(), sizeof(int) * hbuf.size(), st)) return r_;   // (pinned staging: no host sync)
     int* d = m->meta;
     m->d_row_pos = d; m->d_row_start = d + R; m->d_row_end = d + 2 * R; m->d_row_seq = d + 3 * R; m->d_row_token = d + 4 * R;
     m->d_row_frame = d + 5 * R; m->d_row_condframe = d + 6 * R; m->d_row_keep = d + 7 * R;
@@ -787,10 +787,8 @@ static int precompute_time(f5hip_dit* m, const float* t_host, int n_t, hipStream
             host_split_bf16(sv, hi[(size_t)i * 256 + k], lo[(size_t)i * 256 + k]);
             host_split_bf16(cv, hi[(size_t)i * 256 + 128 + k], lo[(size_t)i * 256 + 128 + k]);
         }
-    if (hipMemcpyAsync(m->sinp.hi, hi.data(), hi.size() * 2, hipMemcpyHostToDevice, st) != hipSuccess ||
-        hipMemcpyAsync(m->sinp.lo, lo.data(), lo.size() * 2, hipMemcpyHostToDevice, st) != hipSuccess ||
-        hipStreamSynchronize(st) != hipSuccess)
-        return fail(-6, "time table upload");
+    CK(m->up_time[0].upload(m->sinp.hi, hi.data(), hi.size() * 2, st));
+    CK(m->up_time[1].upload(m->sinp.lo, lo.data(), lo.size() * 2, st));
     GemmArgs g1 = gemm_base(m->sinp, 256, m->time1, n_t);
     g1.act = ACT_SILU; g1.out_hi = m->t1.hi; g1.out_lo = m->t1.lo; g1.ldob = D;
     int r = run_gemm(m, g1, m->time1, EPI_GENERIC, false, 128, st, 128);

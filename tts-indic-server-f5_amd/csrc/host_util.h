@@ -103,6 +103,35 @@ static int pack_linear(PackedW& out, const float* w, int N, int K, int ldw, cons
     return upload_f32(&out.bias, b.data(), b.size());
 }
 
+// Per-call host -> device uploads (row metadata, the sinusoid table) without a host sync: the bytes go through a pinned staging buffer owned by
+// the handle, the copy is queued on the caller's stream, and an event recorded behind it guards the buffer's NEXT use (already complete by then
+// in practice).  The call returns with nothing but stream-ordered work outstanding, so a caller may capture it or keep several streams busy.
+struct HostStage {
+    void* ptr = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool pending = false;
+    int upload(void* dst_dev, const void* src, size_t bytes, hipStream_t st) {
+        if (pending) { (void)hipEventSynchronize(ev); pending = false; }
+        if (bytes > cap) {
+            if (ptr) (void)hipHostFree(ptr);
+            ptr = nullptr; cap = 0;
+            const size_t want = (bytes + 65535) / 65536 * 65536;
+            if (hipHostMalloc(&ptr, want, hipHostMallocDefault) != hipSuccess) { ptr = nullptr; return fail(-5, "hipHostMalloc %zu bytes of staging", want); }
+            cap = want;
+        }
+        if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { ev = nullptr; return fail(-5, "hipEventCreate"); }
+        memcpy(ptr, src, bytes);
+        if (hipMemcpyAsync(dst_dev, ptr, bytes, hipMemcpyHostToDevice, st) != hipSuccess) return fail(-6, "staged upload");
+        if (hipEventRecord(ev, st) != hipSuccess) return fail(-6, "staged upload: event");
+        pending = true;
+        return 0;
+    }
+    void release() {
+        if (pending) (void)hipEventSynchronize(ev);
+        if (ev) (void)hipEventDestroy(ev);
+        if (ptr) (void)hipHostFree(ptr);
+        ptr = nullptr; ev = nullptr; cap = 0; pending = false;
+    }
+};
+
 // fragment-ordered second copy of a one-plane fp16 weight (K a multiple of 128, rows a multiple of 16): GemmArgs::Wf
 static int pack_frag(PackedW& w, hipStream_t st = 0) {
     if (!w.f16 || !w.hi || w.k_pad % 128 || w.ld != w.k_pad || w.n_pad % 16 || w.frag) return 0;
