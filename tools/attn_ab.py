@@ -1,0 +1,13 @@
+#!/usr/bin/env python3
+"""attn3 at the config shapes, HIP events, alternating repeats (for A/B across builds on one box)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from tts_indic_server_f5_amd import ops
+for tag, lens, heads in (("C2  2 x 1404, 16 heads", (1404, 1404), 16), ("C3 share 16 x 1404", (1404,) * 16, 16), ("C5  2 x 2341", (2341, 2341), 16), ("C1  2 x 748, 12 heads", (748, 748), 12)):
+    n, D = sum(lens), 64 * heads
+    g = torch.Generator().manual_seed(1)
+    q, k, v = (torch.randn(n, D, generator=g).cuda() for _ in range(3))
+    fl = sum(4.0 * L * L * 64 * heads for L in lens)
+    us = [ops.attention(q, k, v, lens, heads=heads, impl=3, iters=200)[1] for _ in range(3)]
+    print(f"{tag:26s} " + "  ".join(f"{u:8.2f} us ({fl / u / 1e6 / 2500:.3f})" for u in us), flush=True)

@@ -39,9 +39,10 @@
 // leaves the matrix pipe as s - off, and exp2 applies to it directly -- per score one exp2, one add, half a convert; no max, no subtract,
 // no scale, no rescaling of O, no branch.  fp16 normals span 2^-14 .. 2^16: with the offset 2 binades above the sample maximum the sampled
 // keys have P <= 1/4, the true row maximum has P >= 1/4 (samples are keys), and every P within 2^-12 of it is still a normal number.
-// Whether every probability stayed below fp16's largest finite value is decided ONCE, after the loop, from the largest row sum a lane saw
-// (one v_max per half tile; an inf that an overflowing P put into O is discarded with it): if one did not -- a logit more than 17 binades
-// = 11.8 nats above the query's maximum over its sample -- the WHOLE workgroup redoes its tile with a plain running-maximum loop, correct
+// Whether every probability stayed below fp16's largest finite value is decided ONCE, after the loop, from the row sums themselves (they are
+// accumulated by the matrix pipe from the fp16 probabilities: an overflowed one makes its row sum inf; the inf it put into O is discarded with
+// it): if one did not -- a logit more than 18 binades = 12.5 nats above the query's maximum over its sample -- the WHOLE workgroup redoes its
+// tile with a plain running-maximum loop, correct
 // for any input and exercised by tests/test_gpu_ops.py (k_gain cases).  Because every variant of the kernel (and both key halves of a BAL
 // block) derives the offset from the same sample, variants differ only in the association of fp32 sums.
 // (The running-maximum formulation in the hot loop measured 45.7 us at C2 against 41.4 us for the fixed offset, before any of the
@@ -149,9 +150,25 @@ static __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
     f32x16 oacc[QB][2];
     f32x16 negm[QB];                   // C operand of the first score MFMA of a block = splat(-offset); zero for the first block, fixed after it
     float lrun[QB];
+    // Row sums through the matrix pipe (round 3: the loop is bound by VECTOR issue at head dimension 64 -- 32 v_exp, ~75 other VALU per tile and
+    // wave against 16 MFMAs -- and the sixteen v_add per half tile were its largest item after the exponentials).  One v_mfma_f32_16x16x32_f16
+    // per 16-key k-step with a constant 0 / 1 A operand: seen as a 16 x 16 x 32 B operand, the P^T fragment of lane (fr, fh) is column fr & 15,
+    // k-group 2 fh + (fr >> 4), i.e. k-groups {0, 2} carry query fr & 15 and {1, 3} query 16 + (fr & 15); row 0 of A is ones on k-groups {0, 2},
+    // row 1 on {1, 3}, the rest zero: D[0][n] and D[1][n] accumulate the row sums of queries n and 16 + n (lanes 0-15, registers 0 and 1).  The
+    // sums are those of the fp16-ROUNDED probabilities -- exactly what the P V product multiplies -- and a probability that overflowed fp16 makes
+    // its row sum inf, which is the range check (no v_max in the loop either).
+    f32x4 lacc[QB];
+    f16x8 lones;
+    {
+        const int m16 = lane & 15, kq = lane >> 4;
+        const _Float16 one = ((m16 == 0 && (kq & 1) == 0) || (m16 == 1 && (kq & 1) == 1)) ? (_Float16)1.0f : (_Float16)0.0f;
+#pragma unroll
+        for (int j = 0; j < 8; j++) lones[j] = one;
+    }
 #pragma unroll
     for (int qb = 0; qb < QB; qb++) {
         lrun[qb] = 0.0f;
+        lacc[qb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int g = 0; g < 16; g++) { oacc[qb][0][g] = 0.0f; oacc[qb][1][g] = 0.0f; negm[qb][g] = 0.0f; }
     }
@@ -245,7 +262,6 @@ static __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
     // prefetches K rows of tile kt + 1.
     // H: which half of tile kt `sc` holds.  The block produced here is (kt, 1) for H = 0 and (kt + 1, 0) for H = 1.
     // NEXT_TILE: tile kt + 1 exists.  MASK: the score block produced here belongs to a possibly partial tile.
-    float rs_max = 0.0f;
     struct Frags { f16x8 k[4]; f16x8 v[2][2]; };
     auto fast_half = [&](f32x16 (&sc)[QB], int kt, Frags& use, Frags& fill, auto h_t, auto next_tile_t, auto mask_t) {
         constexpr int H = decltype(h_t)::value;
@@ -276,30 +292,25 @@ static __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(use.k[1], qf[qb][1], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(use.k[2], qf[qb][2], acc, 0, 0, 0);
             }
-            float pe[16], r4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            float pe[16];
             f16x8 pf[2];
 #pragma unroll
-            for (int g = 0; g < 16; g++) {
-                pe[g] = __builtin_amdgcn_exp2f(sc[qb][g]);
-                r4[g & 3] += pe[g];
-            }
+            for (int g = 0; g < 16; g++) pe[g] = __builtin_amdgcn_exp2f(sc[qb][g]);
 #pragma unroll
             for (int s2 = 0; s2 < 2; s2++) {
 #pragma unroll
                 for (int j = 0; j < 8; j++) pf[s2][j] = (_Float16)pe[8 * s2 + j];
 #pragma unroll
                 for (int dt = 0; dt < 2; dt++) oacc[qb][dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(use.v[s2][dt], pf[s2], oacc[qb][dt], 0, 0, 0);
+                lacc[qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(lones, pf[s2], lacc[qb], 0, 0, 0);   // row sums (see lacc)
             }
-            const float rs = (r4[0] + r4[1]) + (r4[2] + r4[3]);
-            lrun[qb] += rs;
-            rs_max = fmaxf(rs_max, rs);   // (v_max drops a NaN operand: an inf - inf cannot occur here, and rows of padding queries are never stored)
             if (HAS_NEXT) sc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(use.k[3], qf[qb][3], acc, 0, 0, 0);
         }
 #pragma unroll
-        for (int i = 0; i < QB * (HAS_NEXT ? 8 : 4); i++) {
+        for (int i = 0; i < QB * (HAS_NEXT ? 10 : 6); i++) {   // (8 + 2 row-sum MFMAs per query block; the VALU left: 16 v_exp, 8 converts, a few moves)
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
         }
         if (HAS_NEXT && (SEG2 || MASK)) {
 #pragma unroll
@@ -326,31 +337,26 @@ static __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[1], qf[0][1], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[2], qf[0][2], acc, 0, 0, 0);
         }
-        float pe[16], r4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        float pe[16];
 #pragma unroll
-        for (int g = 0; g < 16; g++) {
-            pe[g] = __builtin_amdgcn_exp2f(sc[g]);
-            r4[g & 3] += pe[g];
-        }
+        for (int g = 0; g < 16; g++) pe[g] = __builtin_amdgcn_exp2f(sc[g]);
 #pragma unroll
         for (int s2 = 0; s2 < 2; s2++) {
 #pragma unroll
             for (int j = 0; j < 8; j++) pf[s2][j] = (_Float16)pe[8 * s2 + j];
 #pragma unroll
             for (int dt = 0; dt < 2; dt++) oacc[0][dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[s2][dt], pf[s2], oacc[0][dt], 0, 0, 0);
+            lacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(lones, pf[s2], lacc[0], 0, 0, 0);
         }
-        const float rs = (r4[0] + r4[1]) + (r4[2] + r4[3]);
-        lrun[0] += rs;
-        rs_max = fmaxf(rs_max, rs);
         if (NEXT) sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[3], qf[0][3], acc, 0, 0, 0);
-        // the first exp2 / adds / converts run while the fragments are on their way from LDS, then one MFMA : two exp2 : a few VALU
+        // the first exp2 / converts run while the fragments are on their way from LDS, then one MFMA : two exp2 : a few VALU
         __builtin_amdgcn_sched_group_barrier(0x400, 6, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
 #pragma unroll
-        for (int i = 0; i < (NEXT ? 8 : 4); i++) {
+        for (int i = 0; i < (NEXT ? 10 : 6); i++) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x400, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
         }
         if (NEXT) mask_half(sc, kt + 1, H);   // (tests the tile's key count itself)
     };
@@ -411,15 +417,24 @@ static __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
         for (int kt = 0; kt + 1 < nkt; kt++) half_only(sa[0], kt, H1{}, T_{});
         half_only(sa[0], nkt - 1, H1{}, F_{});
     }
-    // Did every probability stay in range?  A lane's row sum over its 16 keys of a half bounds each of them: 2^15 keeps every P a finite fp16
-    // (the fp32 row sums are far from their own range).  (The flag lives in the first bytes of the ring -- 5 x 16 KiB is exactly half a CU's LDS, two workgroups
+    // Did every probability stay in range (l_bad above)?  (The flag lives in the first bytes of the ring -- 5 x 16 KiB is exactly half a CU's LDS, two workgroups
     // per CU -- hence the barriers: everybody done with the ring | flag cleared | flag set | flag read.)
+    // the row sums of this wave's queries out of the 16 x 16 accumulators: query fr sits in lane fr & 15, register fr >> 4.  Kept as before as a
+    // per-lane partial that the epilogue (and the BAL merge) adds over the two lane halves: the whole sum in lanes 0-31, zero in lanes 32-63.
+    bool l_bad = false;
+#pragma unroll
+    for (int qb = 0; qb < QB; qb++) {
+        const float l0 = __shfl(lacc[qb][0], fr & 15, 64), l1 = __shfl(lacc[qb][1], fr & 15, 64);
+        const float lq = (fr >> 4) ? l1 : l0;
+        l_bad = l_bad || !(lq <= 3.0e38f);                 // inf (a probability overflowed fp16) or NaN
+        lrun[qb] = fh ? 0.0f : lq;
+    }
     int* redo_flag = reinterpret_cast<int*>(smem);
     attn_wait_vmcnt<0>();
     __syncthreads();
     if (threadIdx.x == 0) *redo_flag = 0;
     __syncthreads();
-    if (__any(!(rs_max <= A3_P_LIMIT)) && lane == 0) *redo_flag = 1;
+    if (__any(l_bad) && lane == 0) *redo_flag = 1;
     __syncthreads();
     const bool redo = *redo_flag != 0;
     __syncthreads();
