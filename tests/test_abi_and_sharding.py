@@ -166,3 +166,18 @@ def test_strong_mode_sharding_covers_every_unit_once():
     sh = shard_units(ragged, 8)
     loads = [sum(unit_cost(ragged[i]) for i in s) for s in sh]
     assert sorted(sum(sh, [])) == list(range(64)) and max(loads) / min(loads) < 1.08   # LPT dealing balances the cost model
+
+
+def test_torch_library_ops_register_without_a_gpu():
+    """north_star: "host Python calling HIP through PyTorch-ROCm custom ops".  csrc/torch_ops.cpp registers the hot path with TORCH_LIBRARY over
+    the C ABI; the extension must load here (no GPU) and expose the documented schemas (no compute calls: that is tests/test_gpu_dit.py)."""
+    import torch
+    from tts_indic_server_f5_amd import torch_ops
+    assert torch_ops.load(), f"{torch_ops.TORCH_LIB_PATH} missing: run __graft_entry__.build()"
+    schemas = {name: str(getattr(torch.ops.f5hip, name).default._schema) for name in ("cfm_sample", "vocos_decode", "bigvgan_forward")}
+    assert schemas["cfm_sample"] == ("f5hip::cfm_sample(int handle, Tensor dur, Tensor? kv_len, Tensor cond, Tensor cond_mask, Tensor text, Tensor y0, "
+                                     "Tensor t_grid, float cfg_strength) -> Tensor")
+    assert schemas["vocos_decode"] == "f5hip::vocos_decode(int handle, Tensor mel, int hop_length) -> Tensor"
+    assert schemas["bigvgan_forward"] == "f5hip::bigvgan_forward(int handle, Tensor mel, int total_upsample) -> Tensor"
+    with pytest.raises(RuntimeError, match="must be a contiguous fp32 tensor on the HIP device"):   # argument checks run before any device work
+        torch.ops.f5hip.vocos_decode(0, torch.zeros(1, 100, 8), 256)

@@ -310,3 +310,26 @@ def test_two_handles_keep_their_own_attention_mode_and_profile():
     with pytest.raises(F5HipError):
         fast.get_profile()
     inv.set_profiling(False)
+
+
+def test_torch_custom_ops_equal_the_ctypes_path(tiny_model):
+    """torch.ops.f5hip.cfm_sample / vocos_decode (TORCH_LIBRARY, csrc/torch_ops.cpp) and the ctypes binding call the same C entry points: the
+    results are bit-identical, and errors of the library surface as F5HipError either way."""
+    from tts_indic_server_f5_amd import torch_ops
+    from tts_indic_server_f5_amd.vocoder import F5HipVocos
+    assert torch_ops.load()
+    g = torch.Generator().manual_seed(3)
+    cond = torch.randn(2, 12, 100, generator=g)
+    text = torch.randint(0, 40, (2, 14), generator=g)
+    y0 = [torch.randn(40, 100, generator=g), torch.randn(33, 100, generator=g)]
+    kw = dict(steps=3, cfg_strength=2.0, sway_sampling_coef=-1.0, y0=y0)
+    via_ops, _ = tiny_model.sample(cond, text, torch.tensor([40, 33]), **kw)
+    voc = F5HipVocos(synth.vocos_state_dict())
+    w_ops = voc.decode(via_ops.permute(0, 2, 1))
+    try:
+        torch_ops._loaded = False                      # force the ctypes binding
+        via_ctypes, _ = tiny_model.sample(cond, text, torch.tensor([40, 33]), **kw)
+        w_ctypes = voc.decode(via_ctypes.permute(0, 2, 1))
+    finally:
+        torch_ops._loaded = True
+    assert torch.equal(via_ops, via_ctypes) and torch.equal(w_ops, w_ctypes)

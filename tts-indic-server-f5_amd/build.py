@@ -104,7 +104,29 @@ def build(force: bool = False, verbose: bool = True, experiments: bool = False) 
            and not re.search(r"attn3_fwd_kernelILi\dELb\dELb1EE", l)]
     if hot:
         raise RuntimeError("hot kernels use scratch memory: " + ", ".join(hot))
+    build_torch_ops(verbose)
     return LIB
+
+
+TORCH_LIB = os.path.join(CSRC, "libf5hip_torch.so")
+
+
+def build_torch_ops(verbose: bool = True) -> str:
+    """csrc/torch_ops.cpp -> csrc/libf5hip_torch.so: the TORCH_LIBRARY operators (torch.ops.f5hip.*) over the C ABI.  Host C++ only, linked against
+    libf5hip.so (rpath $ORIGIN) and the torch libraries of this interpreter; rebuilt when the source, the header or libf5hip.so changed."""
+    import torch
+    src, hdr = os.path.join(CSRC, "torch_ops.cpp"), os.path.join(os.path.dirname(HERE), "include", "f5hip.h")
+    if os.path.exists(TORCH_LIB) and all(os.path.getmtime(d) <= os.path.getmtime(TORCH_LIB) for d in (src, hdr, LIB)):
+        return TORCH_LIB
+    tdir = os.path.dirname(torch.__file__)
+    cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+           f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}", f"-I{tdir}/include", f"-I{tdir}/include/torch/csrc/api/include",
+           "-I/opt/rocm/include", "-o", TORCH_LIB, src, f"-L{CSRC}", "-lf5hip", f"-L{tdir}/lib", "-ltorch", "-ltorch_cpu", "-lc10", "-lc10_hip",
+           "-Wl,-rpath,$ORIGIN", f"-Wl,-rpath,{tdir}/lib"]
+    if verbose:
+        print("[build]", " ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return TORCH_LIB
 
 
 if __name__ == "__main__":

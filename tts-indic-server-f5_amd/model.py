@@ -13,7 +13,7 @@ from dataclasses import dataclass
 import numpy as np
 import torch
 
-from . import _lib
+from . import _lib, torch_ops
 from .tokenizer import list_str_to_idx
 
 
@@ -287,10 +287,17 @@ class F5HipModel:
         text_np = _i32(text.numpy())
         tg = np.ascontiguousarray(t.numpy().astype(np.float32))
         d_np, kv_np = _i32(lay), _i32(durs)
-        _lib.check(self._lib.f5hip_cfm_sample_masked(
-            self._h, batch, _ptr(d_np), _ptr(kv_np) if padded else None, _ptr(cond_packed), _ptr(mask_packed), _ptr(text_np),
-            text_np.shape[1], _ptr(y0_packed), _ptr(tg), steps, float(cfg_strength), _ptr(out_packed), _lib.current_stream_ptr()),
-            "f5hip_cfm_sample")
+        if torch_ops.load():   # the TORCH_LIBRARY operator over the same C entry point (csrc/torch_ops.cpp)
+            try:
+                out_packed = torch_ops.ops().cfm_sample(int(self._h), torch.from_numpy(d_np), torch.from_numpy(kv_np) if padded else None, cond_packed,
+                                                        torch.from_numpy(mask_packed), torch.from_numpy(text_np), y0_packed, torch.from_numpy(tg), float(cfg_strength))
+            except RuntimeError as e:
+                raise _lib.F5HipError(str(e).split("\n")[0]) from None
+        else:
+            _lib.check(self._lib.f5hip_cfm_sample_masked(
+                self._h, batch, _ptr(d_np), _ptr(kv_np) if padded else None, _ptr(cond_packed), _ptr(mask_packed), _ptr(text_np),
+                text_np.shape[1], _ptr(y0_packed), _ptr(tg), steps, float(cfg_strength), _ptr(out_packed), _lib.current_stream_ptr()),
+                "f5hip_cfm_sample")
         if all(n == nmax for n in lay):
             out = out_packed.view(batch, nmax, self.num_channels)
         else:

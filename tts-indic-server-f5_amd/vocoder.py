@@ -9,7 +9,7 @@ import ctypes as C
 import numpy as np
 import torch
 
-from . import _lib
+from . import _lib, torch_ops
 
 
 class F5HipVocos:
@@ -48,6 +48,8 @@ class F5HipVocos:
     def decode(self, mel: torch.Tensor) -> torch.Tensor:
         b, c, t = mel.shape
         mel = mel.to(self.device, torch.float32).contiguous()
+        if torch_ops.load():   # TORCH_LIBRARY operator over the same C entry point
+            return torch_ops.ops().vocos_decode(int(self._h), mel, self.hop_length)
         wave = torch.empty(b, self.hop_length * (t - 1), device=self.device, dtype=torch.float32)
         _lib.check(self._lib.f5hip_vocos_decode(self._h, b, t, C.c_void_p(mel.data_ptr()), C.c_void_p(wave.data_ptr()),
                                                 _lib.current_stream_ptr()), "f5hip_vocos_decode")
@@ -109,6 +111,8 @@ class F5HipBigVGAN:
     def __call__(self, mel: torch.Tensor) -> torch.Tensor:
         b, c, t = mel.shape
         mel = mel.to(self.device, torch.float32).contiguous()
+        if torch_ops.load():
+            return torch_ops.ops().bigvgan_forward(int(self._h), mel, self.total_up)
         wave = torch.empty(b, 1, self.total_up * t, device=self.device, dtype=torch.float32)
         _lib.check(self._lib.f5hip_bigvgan_forward(self._h, b, t, C.c_void_p(mel.data_ptr()), C.c_void_p(wave.data_ptr()),
                                                    _lib.current_stream_ptr()), "f5hip_bigvgan_forward")
