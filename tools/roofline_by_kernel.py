@@ -25,11 +25,13 @@ def main():
     ap.add_argument("--frames", type=int, default=1404)
     ap.add_argument("--dim", type=int, default=1024)
     ap.add_argument("--heads", type=int, default=16)
+    ap.add_argument("--cus", type=int, default=256)
     a = ap.parse_args()
     n_seq = 2 * a.batch
     m_real, m_pad = n_seq * a.frames, n_seq * ((a.frames + 127) // 128 * 128)
     rows = list(csv.DictReader(open(a.csv)))
     total = sum(float(r["TotalDurationNs"]) for r in rows)
+    qkv_calls = max([int(r["Calls"]) for r in rows if re.match(r"gemm6_kernel<true, [1-9]", r["Name"])] or [0])
     print(f"# {a.csv}: batch {a.batch} ({n_seq} sequences of {a.frames} frames, M = {m_real} real / {m_pad} padded rows); device time in the trace {total / 1e6:.1f} ms")
     print(f"# {'kernel':58s} {'grid':>10s} {'calls':>6s} {'avg us':>9s} {'% time':>7s}  {'work / launch':>16s}  {'achieved':>14s}  frac of roof")
     for r in rows:
@@ -47,18 +49,25 @@ def main():
             else:
                 epi, rbw = int(m6.group(1)), int(m6.group(2))
                 tiles_m, bn = -(-m_pad // (256 if rbw == 8 else 176)), 256
-            if wgs % tiles_m:
+            if m6 and wgs == a.cus:
+                # persistent grid (one workgroup per CU walks the tiles): the grid no longer tells N.  EPI != 0 is the QKV launch; the EPI 0
+                # instantiations are told apart by their call count relative to QKV's (1x: FF1, 2x: out + FF2, 3x: all three share the kernel)
+                ratio = calls / max(1, qkv_calls)
+                tag, nk = ("QKV", 3.0) if epi else (("FF1", 2.0) if ratio < 1.5 else (("out + FF2 (mean)", 1.5) if ratio < 2.5 else ("FF1 + out + FF2 (mean)", 5.0 / 3.0)))
+                fl = 2.0 * m_real * a.dim * a.dim * nk
+            elif wgs % tiles_m:
                 continue
-            n = wgs // tiles_m * bn
-            k = 1536 if (n == a.dim and not epi) else a.dim
-            tag = "QKV" if epi else ("FF1" if n == 2 * a.dim else ("out + FF2 (mean)" if n == a.dim else f"N = {n}"))
-            fl = 2.0 * m_real * n * k
+            else:
+                n = wgs // tiles_m * bn
+                k = 1536 if (n == a.dim and not epi) else a.dim
+                tag = "QKV" if epi else ("FF1" if n == 2 * a.dim else ("out + FF2 (mean)" if n == a.dim else f"N = {n}"))
+                fl = 2.0 * m_real * n * k
             work, unit, frac = f"{fl / 1e9:9.2f} GFLOP", f"{fl / avg / 1e6:8.1f} TF/s", fl / avg / 1e6 / PEAK_TF
             name = f"{name[:44]} [{tag}]"
         elif name.startswith("attn3_fwd_kernel"):
             fl = 4.0 * a.frames * a.frames * 64 * a.heads * n_seq
             work, unit, frac = f"{fl / 1e9:9.2f} GFLOP", f"{fl / avg / 1e6:8.1f} TF/s", fl / avg / 1e6 / PEAK_TF
-        elif name.startswith("ln_kernel<4>"):
+        elif name.startswith("ln_kernel<4"):
             by = m_real * a.dim * 6.0
             work, unit, frac = f"{by / 1e6:9.2f} MB   ", f"{by / avg / 1e3:8.1f} GB/s", by / avg / 1e3 / PEAK_GBS
         if work is None:
