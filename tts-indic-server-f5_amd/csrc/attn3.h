@@ -146,6 +146,15 @@ static __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
         }
     };
     static_assert((NST - 2) * P_HI <= 32, "wait_landed covers 32 outstanding pieces");
+    // the same wait with a compile-time tile count: the steady state of the ring.  (The switch above compiles to a chain of ~27 scalar
+    // compare / branch pairs; tools/attn_stamps.py showed 240-500 clocks per KV tile between the end of a tile and the end of its wait with
+    // every piece long landed -- the hot loop takes this path, the switch serves the first and last tiles.)
+    auto wait_landed_steady = [&](auto t_) {
+        constexpr int T = decltype(t_)::value;
+        if constexpr (P_HI == P_LO) attn_wait_vmcnt<T * P_HI>();
+        else if (mine == P_HI) attn_wait_vmcnt<T * P_HI>();
+        else attn_wait_vmcnt<T * P_LO>();
+    };
 
     f32x16 oacc[QB][2];
     f32x16 negm[QB];                   // C operand of the first score MFMA of a block = splat(-offset); zero for the first block, fixed after it
@@ -173,7 +182,9 @@ static __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
         for (int g = 0; g < 16; g++) { oacc[qb][0][g] = 0.0f; oacc[qb][1][g] = 0.0f; negm[qb][g] = 0.0f; }
     }
 
-    unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_prev = 0;
+    unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_prev = 0, st_t0 = 0, st_pro = 0;
+    unsigned long long st_r0 = 0;
+    if (STAMPS) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_t0)::"memory"); st_r0 = __builtin_amdgcn_s_memrealtime(); }
     const bool st_on = STAMPS && p.dbg != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && wave == 0;
 #define A3_STAMP(I)                                                                                  \
     if (STAMPS && st_on) {                                                                           \
@@ -239,7 +250,8 @@ static __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
         if (PAIR) {
             if ((kt & 1) || kt == 0) return;
             // issued so far: tiles up to kt - 3 + NST (capped at nkt - 1); tiles kt + 1, kt + 2 must have landed
-            wait_landed(max(0, min(kt - 3 + NST, nkt - 1) - (kt + 2)));
+            if (kt - 3 + NST <= nkt - 1) wait_landed_steady(std::integral_constant<int, NST - 5>{});
+            else wait_landed(max(0, nkt - 1 - (kt + 2)));
             A3_STAMP(5);
             __builtin_amdgcn_s_barrier();
             A3_STAMP(4);
@@ -247,7 +259,8 @@ static __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
             if (kt - 1 + NST < nkt) issue_tile(kt - 1 + NST);
             return;
         }
-        wait_landed(min(NST - 3, nkt - 2 - kt));   // tiles kt + 2 .. kt + NST - 2 may stay in flight
+        if (nkt - 2 - kt >= NST - 3) wait_landed_steady(std::integral_constant<int, NST - 3>{});   // tiles kt + 2 .. kt + NST - 2 may stay in flight
+        else wait_landed(nkt - 2 - kt);
         A3_STAMP(5);
         __builtin_amdgcn_s_barrier();
         A3_STAMP(4);
@@ -391,6 +404,7 @@ static __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
         v_read(fa.v[1], stage_of(0) + v_lane, 0, 1);
     }
     A3_STAMP(-1);
+    st_pro = st_prev - st_t0;
     using T_ = std::true_type;
     using F_ = std::false_type;
     using H0 = std::integral_constant<int, 0>;
@@ -519,8 +533,7 @@ static __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
         }
         if (role == 2) return;   // (no barrier after this point)
     }
-    if (STAMPS && st_on && lane == 0) { p.dbg[0] = st_acc[0]; p.dbg[1] = st_acc[1]; p.dbg[2] = st_acc[2]; p.dbg[3] = (unsigned long long)nkt; p.dbg[4] = st_acc[4]; p.dbg[5] = st_acc[5]; }
-#undef A3_STAMP
+    if (STAMPS && st_on && lane == 0) { p.dbg[0] = st_acc[0]; p.dbg[1] = st_acc[1]; p.dbg[2] = st_acc[2]; p.dbg[3] = (unsigned long long)nkt; p.dbg[4] = st_acc[4]; p.dbg[5] = st_acc[5]; p.dbg[6] = st_pro; }
 
 #pragma unroll
     for (int qb = 0; qb < QB; qb++) {
@@ -548,4 +561,7 @@ static __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
                 }
         }
     }
+    A3_STAMP(-1);
+    if (STAMPS && st_on && lane == 0) { p.dbg[7] = st_prev - st_t0; p.dbg[8] = __builtin_amdgcn_s_memrealtime() - st_r0; }   // (stores issued, not retired)
+#undef A3_STAMP
 }

@@ -94,33 +94,37 @@ extern "C" int f5hip_debug_gemm_bench(int32_t M, int32_t N, int32_t K, int32_t p
     return 0;
 }
 
-// per-phase cycle totals of one wave of attn3 (ring wait + barrier | QK^T issue | softmax + PV) and the kernel's average duration
-extern "C" int f5hip_debug_attn_stamps(int32_t n, int32_t heads, int32_t iters, unsigned long long* out, double* avg_us) {
-    const int D = heads * 64, n_seq = 2, pitch = (n + 127) / 128 * 128, M = n_seq * pitch + 256;
-    float* f = nullptr; __bf16 *qk = nullptr, *vt = nullptr, *oh = nullptr, *ol = nullptr, *lo_tmp = nullptr; int* meta = nullptr; unsigned long long* dbg = nullptr;
+// per-phase cycle totals of one wave of attn3 (ring wait + barrier | QK^T issue | softmax + PV) and the kernel's average duration.
+// n_seq = 2 with 1152 < n <= 1536: the balanced 8-wave kernel of C2; n_seq > 2: the 4-wave kernel of the batch shapes; n <= 768: 64 queries per wave
+extern "C" int f5hip_debug_attn_stamps(int32_t n, int32_t heads, int32_t n_seq, int32_t iters, unsigned long long* out, double* avg_us) {
+    const int D = heads * 64, pitch = (n + 127) / 128 * 128, M = n_seq * pitch + 256;
+    if (n_seq < 1 || n_seq > 64) return fail(-1, "attn stamps: n_seq");
+    float* f = nullptr; __bf16 *qk = nullptr, *vt = nullptr, *oh = nullptr; int* meta = nullptr; unsigned long long* dbg = nullptr;
     const size_t nq = (size_t)M * 2 * D, nv = (size_t)D * M;
-    if (hipMalloc(&f, nq * 4) || hipMalloc(&qk, nq * 2) || hipMalloc(&vt, nv * 2) || hipMalloc(&oh, (size_t)M * D * 2) || hipMalloc(&ol, (size_t)M * D * 2) ||
-        hipMalloc(&meta, 6 * sizeof(int)) || hipMalloc(&dbg, 64) || hipMalloc(&lo_tmp, nq * 2)) return fail(-5, "attn stamps: hipMalloc");
+    if (hipMalloc(&f, nq * 4) || hipMalloc(&qk, nq * 2) || hipMalloc(&vt, nv * 2) || hipMalloc(&oh, (size_t)M * D * 2) ||
+        hipMalloc(&meta, 3 * 64 * sizeof(int)) || hipMalloc(&dbg, 128)) return fail(-5, "attn stamps: hipMalloc");
     hipLaunchKernelGGL(fill_pattern_kernel, dim3((nq + 255) / 256), dim3(256), 0, 0, f, nq, 3u);
-    hipLaunchKernelGGL(pack_weight_kernel, dim3(M), dim3(256), 0, 0, f, M, 2 * D, 2 * D, qk, lo_tmp, 2 * D);   // hi plane = bf16(q | k); the lo plane is discarded
-    hipLaunchKernelGGL(pack_weight_kernel, dim3(D), dim3(256), 0, 0, f, D, M, M, vt, lo_tmp, M);
-    const int h_meta[6] = {0, pitch, n, n, n, n};
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(M), dim3(256), 0, 0, f, M, 2 * D, 2 * D, qk, (__bf16*)nullptr, 2 * D);   // one fp16 plane (q | k)
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(D), dim3(256), 0, 0, f, D, M, M, vt, (__bf16*)nullptr, M);
+    int h_meta[3 * 64];
+    for (int i = 0; i < n_seq; i++) { h_meta[i] = i * pitch; h_meta[64 + i] = n; h_meta[128 + i] = n; }
     hipMemcpy(meta, h_meta, sizeof(h_meta), hipMemcpyHostToDevice);
-    hipMemset(dbg, 0, 64);
+    hipMemset(dbg, 0, 128);
     AttnArgs at; memset(&at, 0, sizeof(at));
-    at.qk = qk; at.vt = vt; at.D = D; at.ldvt = M; at.seq_row0 = meta; at.seq_len = meta + 2; at.seq_kvlen = meta + 4; at.out_hi = oh; at.out_lo = ol; at.dbg = dbg;
+    at.qk = qk; at.vt = vt; at.D = D; at.ldvt = M; at.seq_row0 = meta; at.seq_len = meta + 64; at.seq_kvlen = meta + 128; at.out_hi = oh; at.f16_out = 1; at.dbg = dbg;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int it = -2; it < iters; it++) {
         if (it == 0) hipEventRecord(e0, 0);
-        if (n <= 768) hipLaunchKernelGGL((attn3_fwd_kernel<4, false, true, 9, 2>), dim3((n + 255) / 256, heads, n_seq), dim3(256), 0, 0, at);   // 64 queries per wave   // one wave per SIMD, one workgroup per CU at heads = 12
-        else hipLaunchKernelGGL((attn3_fwd_kernel<6, false, true, 9>), dim3((n + 191) / 192, heads, n_seq), dim3(384), 0, 0, at);
+        if (n <= 768 && n_seq == 2) hipLaunchKernelGGL((attn3_fwd_kernel<4, false, true, 9, 2>), dim3((n + 255) / 256, heads, n_seq), dim3(256), 0, 0, at);
+        else if (n_seq == 2) hipLaunchKernelGGL((attn3_fwd_kernel<8, false, true, 9, 1, true>), dim3((n + 191) / 192, heads, n_seq), dim3(512), 0, 0, at);
+        else hipLaunchKernelGGL((attn3_fwd_kernel<4, false, true, 5>), dim3((n + 127) / 128, heads, n_seq), dim3(256), 0, 0, at);
     }
     hipEventRecord(e1, 0); hipEventSynchronize(e1);
     float ms = 0; hipEventElapsedTime(&ms, e0, e1);
     if (avg_us) *avg_us = (double)ms * 1e3 / iters;
-    hipMemcpy(out, dbg, 48, hipMemcpyDeviceToHost);
+    hipMemcpy(out, dbg, 72, hipMemcpyDeviceToHost);
     hipError_t e = hipGetLastError();
-    for (void* p : {(void*)f, (void*)qk, (void*)vt, (void*)oh, (void*)ol, (void*)meta, (void*)dbg, (void*)lo_tmp}) hipFree(p);
+    for (void* p : {(void*)f, (void*)qk, (void*)vt, (void*)oh, (void*)meta, (void*)dbg}) hipFree(p);
     if (e != hipSuccess) return fail(-7, "attn stamps: %s", hipGetErrorString(e));
     return 0;
 }

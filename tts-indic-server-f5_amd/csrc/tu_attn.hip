@@ -70,8 +70,11 @@ hipError_t f5_launch_attn3(const AttnArgs& a, int max_len, int heads, int n_seq,
         const long long cost = ((wgs + 255) / 256) * nw;
         if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = nw; }
     }
+    static const int force_nw = getenv("F5HIP_ATTN_NW") ? atoi(getenv("F5HIP_ATTN_NW")) : 0;        // diagnostics (tools/attn_ab.py): 4 | 6 | 8 waves
+    static const int force_deep = getenv("F5HIP_ATTN_DEEP") ? atoi(getenv("F5HIP_ATTN_DEEP")) : -1;   // 1: the 9-stage ring (one workgroup per CU)
+    if (force_nw == 4 || force_nw == 6 || force_nw == 8) best = force_nw;
     const dim3 grid((max_len + 32 * best - 1) / (32 * best), heads, n_seq);
-    const bool deep = best >= 6 && (long long)grid.x * grid.y * grid.z <= 256;
+    const bool deep = best >= 6 && (force_deep >= 0 ? force_deep != 0 : (long long)grid.x * grid.y * grid.z <= 256);
     const bool invariant = a.shape_invariant < 0 ? g_attn_shape_invariant != 0 : a.shape_invariant != 0;
     const bool bal = best == 6 && !no_bal && !invariant;
     if (a.seq_kv2_row0) attn3_launch<true>(a, best, deep, bal, grid, st);
