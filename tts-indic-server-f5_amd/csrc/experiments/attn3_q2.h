@@ -1,3 +1,7 @@
+// RECORD of a measured-and-rejected variant (round 3): attn3.h with a "Q2" step -- 64 queries per wave so that every K / V^T fragment read from LDS
+// feeds two MFMAs, the two query blocks pipelined against each other inside the wave (MFMAs as asm with explicit VGPR / AGPR files, exp2 / converts
+// of the other block hand-placed between them behind sched_barrier fences, one fragment set refilled in place).  Correct, slower than attn3's
+// 32-query waves at two per SIMD in every shape; numbers and the reasons in profiles/r03_attn_ablate.txt.  Not included by any translation unit.
 // attn3: flash-style attention forward.  S^T = K Q^T, so a query is a lane and its row statistics are in-register; exp(S) is directly the
 // B operand of O^T += V^T P^T.  A wave owns QB blocks of 32 queries; a workgroup = NW waves = one query tile of 32 QB NW queries; K / V^T
 // tiles of 64 keys stream through an LDS ring by LDS-DMA.
@@ -49,10 +53,7 @@
 // scheduling work.)
 #define A3_OFF_MARGIN 2.0f
 #ifndef A3_ABL
-// timing ablations of the hot loop (WRONG results, diagnostics only; tools/attn_ablate.sh builds one library per value and profiles/r03_attn_ablate.txt
-// holds the result): bit 0 no ring step (no wait / barrier / refill), bit 1 exp2 -> v_mul, bit 2 no LDS fragment reads, bit 3 no P V / row-sum MFMAs,
-// bit 4 no KV loop at all (launch + prologue + epilogue)
-#define A3_ABL 0
+#define A3_ABL 0   // timing ablations of the hot loop (WRONG results; tools/attn_ablate.sh): bit 0 no ring step, bit 1 exp2 -> v_mul, bit 2 no LDS reads, bit 3 no P V
 #endif
 #define A3_P_LIMIT 0x1p15f
 // BAL (NW = 8, QB = 1, 192 queries per workgroup): the SIMD-balanced form of the 6-block tile.  Eight waves put two on every SIMD; waves 0-3 own a
@@ -60,7 +61,7 @@
 // so every SIMD carries three half tiles per tile (with six whole-block waves two SIMDs carry four and two carry two, and the per-tile barrier
 // makes the four the pace).  The two halves of blocks 4 / 5 keep their own offset, O and l and are merged once at the end through LDS.
 template <int NW, bool SEG2 = false, bool STAMPS = false, int NST = 5, int QB = 1, bool BAL = false>
-static __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(QB == 2 ? 1 : 2, QB == 2 ? 1 : 2))) void attn3_fwd_kernel(const AttnArgs p) {
+static __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu((QB == 2 && NST >= 9) ? 1 : 2, (QB == 2 && NST >= 9) ? 1 : 2))) void attn3_fwd_kernel(const AttnArgs p) {
     constexpr int STAGE = 16384;   // one 64-key tile: 8 KiB of K rows + 8 KiB of V^T rows
     constexpr int P_HI = (16 + NW - 1) / NW, P_LO = 16 / NW;   // 1 KiB pieces of a KV tile per wave (pieces w, w + NW, ...)
     static_assert(!BAL || (NW == 8 && QB == 1), "BAL is the 8-wave, 6-block form");
@@ -111,10 +112,8 @@ static __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
 #pragma unroll
         for (int s = 0; s < 4; s++) ksamp[s] = *reinterpret_cast<const f16x8*>(krow + s * 16);
     }
-
     // Retire the Q / sample loads BEFORE the first LDS-DMA is issued: with a DMA in flight hipcc can only wait vmcnt(0) for an
-    // ordinary VGPR load, and it would put that wait inside the KV loop, draining the ring every tile.  (Issuing tile 0's DMA in front of
-    // this point, so that the two latencies overlap, measured no different: profiles/r03_attn_ablate.txt.)
+    // ordinary VGPR load, and it would put that wait inside the KV loop, draining the ring every tile.
 #pragma unroll
     for (int qb = 0; qb < QB; qb++) asm volatile("" ::"v"(qf[qb][0]), "v"(qf[qb][1]), "v"(qf[qb][2]), "v"(qf[qb][3]) : "memory");
     asm volatile("" ::"v"(ksamp[0]), "v"(ksamp[1]), "v"(ksamp[2]), "v"(ksamp[3]) : "memory");
@@ -294,19 +293,20 @@ static __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
         }
         // prefetch for the following half tile: H = 0 -> (kt, 1) multiplies K(kt + 1, rows 0-31) and V(kt, keys 32-63);
         //                                      H = 1 -> (kt + 1, 0) multiplies K(kt + 1, rows 32-63) and V(kt + 1, keys 0-31)
-        if (A3_ABL & 4) {
+        if (false) {
+        } else if (A3_ABL & 4) {
             fill = use;
         } else {
-            if (NEXT_TILE) qk_read(fill.k, kt + 1, H == 0 ? 0 : 1);
-            if (H == 0) {
-                const unsigned vb = stage_of(kt) + v_lane;
-                v_read(fill.v[0], vb, 1, 0);
-                v_read(fill.v[1], vb, 1, 1);
-            } else if (NEXT_TILE) {
-                const unsigned vb = stage_of(kt + 1) + v_lane;
-                v_read(fill.v[0], vb, 0, 0);
-                v_read(fill.v[1], vb, 0, 1);
-            }
+        if (NEXT_TILE) qk_read(fill.k, kt + 1, H == 0 ? 0 : 1);
+        if (H == 0) {
+            const unsigned vb = stage_of(kt) + v_lane;
+            v_read(fill.v[0], vb, 1, 0);
+            v_read(fill.v[1], vb, 1, 1);
+        } else if (NEXT_TILE) {
+            const unsigned vb = stage_of(kt + 1) + v_lane;
+            v_read(fill.v[0], vb, 0, 0);
+            v_read(fill.v[1], vb, 0, 1);
+        }
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -387,6 +387,122 @@ static __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
         if (NEXT) mask_half(sc, kt + 1, H);   // (tests the tile's key count itself)
     };
 
+    // ---- Q2 (QB = 2 at two waves per SIMD, NST = 5): 64 queries per wave, so every K / V^T fragment read from LDS feeds TWO MFMAs -- the LDS
+    // pipe was the co-bottleneck of the 32-query wave (one 1 KiB fragment read per 32-clock MFMA is exactly the CU's 128 B / clk; ablations in
+    // profiles/r03_attn_ablate.txt: no LDS reads -12..14 %, exp2 -> v_mul only -3 %).  256 registers hold ONE fragment set and no spare score
+    // block, so a half-tile step is two regions that pipeline the two query blocks against each other inside the wave:
+    //   region 1: MFMAs of block 0 (next scores -> sc[0], O[0] += V P0, row sums)  ||  exp2 / convert of block 1 (sc[1] -> p1)
+    //   region 2: MFMAs of block 1 (next scores -> sc[1], O[1] += V P1, row sums)  ||  exp2 / convert of block 0's NEW scores (sc[0] -> p0)
+    // p0 (8 registers) crosses the step boundary; the partner wave on the SIMD covers LDS latency (fragments are read at the top of the step).
+    constexpr bool Q2 = QB == 2;
+    // MFMAs of the Q2 step as asm with explicit register files: score blocks (read by v_exp) and the offsets (their C operand: acc_cd is ONE bit
+    // for C and D) in VGPRs, O and the row sums in AGPRs.  Left to hipcc the offsets went to AGPRs, so the scores did too, and every score cost a
+    // v_accvgpr_read before its exp2 (64 extra VALU per tile, s_nop 11 behind the chain).  asm volatile also pins the MFMA order; the groups
+    // below are fenced with sched_barrier(0), which hand-places the VALU of the other query block between them.
+    auto mf_first = [&](f32x16& d, const f16x8& a_, const f16x8& b_, const f32x16& c_) {
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "+v"(d) : "v"(a_), "v"(b_), "v"(c_));   // ("+": the block keeps its registers round the loop)
+    };
+    auto mf_acc_v = [&](f32x16& d, const f16x8& a_, const f16x8& b_) {
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(d) : "v"(a_), "v"(b_));
+    };
+    // (at two waves per SIMD hipcc splits the 256 registers 128 : 128 as soon as anything is pinned to an AGPR: everything in VGPRs there)
+    auto mf_acc_a = [&](f32x16& d, const f16x8& a_, const f16x8& b_) {
+        if constexpr (NST >= 9) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(d) : "v"(a_), "v"(b_));
+        else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(d) : "v"(a_), "v"(b_));
+    };
+    auto mf_sum_a = [&](f32x4& d, const f16x8& a_, const f16x8& b_) {
+        if constexpr (NST >= 9) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(d) : "v"(a_), "v"(b_));
+        else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(d) : "v"(a_), "v"(b_));
+    };
+    typedef __attribute__((ext_vector_type(2))) float f32x2_;
+    typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_;
+    f16x8 p0[2];
+    // exp2 of scores [G0, G1) of a block and the packed converts of the pairs [C0, C1) (a pair = scores 2c, 2c + 1 -> element c of the P fragments)
+    auto q2_exp = [&](f32x16& sc, auto g0_, auto g1_) {
+#pragma unroll
+        for (int g = decltype(g0_)::value; g < decltype(g1_)::value; g++) sc[g] = (A3_ABL & 2) ? sc[g] * 0.001f : __builtin_amdgcn_exp2f(sc[g]);
+    };
+    auto q2_cvt = [&](const f32x16& sc, f16x8 (&pf)[2], auto c0_, auto c1_) {
+#pragma unroll
+        for (int c = decltype(c0_)::value; c < decltype(c1_)::value; c++) {
+            const f16x2_ h = __builtin_convertvector((f32x2_){sc[2 * c], sc[2 * c + 1]}, f16x2_);
+            pf[c >> 2][(c & 3) * 2] = h[0];
+            pf[c >> 2][(c & 3) * 2 + 1] = h[1];
+        }
+    };
+    auto q2_softmax = [&](f32x16& sc, f16x8 (&pf)[2]) {
+        using I0 = std::integral_constant<int, 0>;
+        q2_exp(sc, I0{}, std::integral_constant<int, 16>{});
+        q2_cvt(sc, pf, I0{}, std::integral_constant<int, 8>{});
+    };
+#define A3_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define A3_I(N) std::integral_constant<int, N> {}
+    // one region: MFMAs of block A (next scores -> sa, O[A] += V pa, row sums)  ||  exp2 / convert of block B (sb -> pb)
+    auto q2_region = [&](f32x16& sa_, const f32x16& negm_a, const f16x8 (&qa)[4], f32x16 (&oa)[2], f32x4& la, const f16x8 (&pa)[2],
+                         f32x16& sb_, f16x8 (&pb)[2], Frags& fr, auto next_t, auto soft_t, auto&& after_qk) {
+        constexpr bool NEXT = decltype(next_t)::value, SOFT = decltype(soft_t)::value;
+        A3_FENCE();
+        if (NEXT) mf_first(sa_, fr.k[0], qa[0], negm_a);
+        if (SOFT) q2_exp(sb_, A3_I(0), A3_I(2));
+        A3_FENCE();
+        if (NEXT) mf_acc_v(sa_, fr.k[1], qa[1]);
+        if (SOFT) { q2_exp(sb_, A3_I(2), A3_I(4)); q2_cvt(sb_, pb, A3_I(0), A3_I(1)); }
+        A3_FENCE();
+        if (NEXT) mf_acc_v(sa_, fr.k[2], qa[2]);
+        if (SOFT) { q2_exp(sb_, A3_I(4), A3_I(6)); q2_cvt(sb_, pb, A3_I(1), A3_I(2)); }
+        A3_FENCE();
+        if (NEXT) mf_acc_v(sa_, fr.k[3], qa[3]);
+        if (SOFT) { q2_exp(sb_, A3_I(6), A3_I(8)); q2_cvt(sb_, pb, A3_I(2), A3_I(3)); }
+        A3_FENCE();
+        after_qk();
+        mf_acc_a(oa[0], fr.v[0][0], pa[0]);
+        if (SOFT) { q2_exp(sb_, A3_I(8), A3_I(10)); q2_cvt(sb_, pb, A3_I(3), A3_I(4)); }
+        A3_FENCE();
+        mf_acc_a(oa[1], fr.v[0][1], pa[0]);
+        if (SOFT) { q2_exp(sb_, A3_I(10), A3_I(12)); q2_cvt(sb_, pb, A3_I(4), A3_I(5)); }
+        A3_FENCE();
+        mf_sum_a(la, lones, pa[0]);
+        if (SOFT) q2_exp(sb_, A3_I(12), A3_I(14));
+        A3_FENCE();
+        mf_acc_a(oa[0], fr.v[1][0], pa[1]);
+        if (SOFT) { q2_exp(sb_, A3_I(14), A3_I(16)); q2_cvt(sb_, pb, A3_I(5), A3_I(6)); }
+        A3_FENCE();
+        mf_acc_a(oa[1], fr.v[1][1], pa[1]);
+        if (SOFT) q2_cvt(sb_, pb, A3_I(6), A3_I(8));
+        A3_FENCE();
+        mf_sum_a(la, lones, pa[1]);
+        A3_FENCE();
+    };
+    // Q2 (QB = 2: 64 queries per wave, one wave per SIMD): every K / V^T fragment read from LDS feeds TWO MFMAs -- the LDS pipe was the
+    // co-bottleneck of the 32-query wave (one 1 KiB fragment per 32-clock MFMA is exactly the CU's 128 B / clk; profiles/r03_attn_ablate.txt:
+    // no LDS reads -12..14 %, exp2 -> v_mul only -3 %).  A half-tile step is two regions that pipeline the two query blocks against each
+    // other inside the wave: region 1 = MFMAs of block 0 || softmax of block 1, region 2 = MFMAs of block 1 || softmax of block 0's NEW scores.
+    // p0 (the converted probabilities of block 0) crosses the step boundary.
+    auto q2_step = [&](f32x16 (&sc)[QB], int kt, Frags& fr, auto h_t, auto next_tile_t, auto mask_t) {
+        constexpr int H = decltype(h_t)::value;
+        constexpr bool NEXT_TILE = decltype(next_tile_t)::value, MASK = decltype(mask_t)::value;
+        constexpr bool HAS_NEXT = H == 0 || NEXT_TILE;
+        constexpr int QB1 = QB - 1;   // (= 1; keeps the QB = 1 instantiations well-formed)
+        if (H == 0 && !(A3_ABL & 1)) ring_step(kt);
+        // ONE fragment set, refilled in place: the V^T fragments of this step here (first used five MFMA groups on), the K fragments of the
+        // FOLLOWING step in the middle of region 2, when the last score MFMA of this step has read them (six groups before their first use)
+        if (!(A3_ABL & 4)) {
+            const unsigned vb = stage_of(kt) + v_lane;
+            v_read(fr.v[0], vb, H, 0);
+            v_read(fr.v[1], vb, H, 1);
+        }
+        f16x8 p1[2];
+        using N_ = std::integral_constant<bool, HAS_NEXT>;
+        q2_region(sc[0], negm[0], qf[0], oacc[0], lacc[0], p0, sc[QB1], p1, fr, N_{}, std::true_type{}, [] {});
+        if (HAS_NEXT && (SEG2 || MASK)) { asm volatile("s_nop 15\n\ts_nop 7" ::: "memory"); mask_half(sc[0], H == 0 ? kt : kt + 1, H == 0 ? 1 : 0); }
+        q2_region(sc[QB1], negm[QB1], qf[QB1], oacc[QB1], lacc[QB1], p1, sc[0], p0, fr, N_{}, N_{}, [&] {
+            if (NEXT_TILE && !(A3_ABL & 4)) qk_read(fr.k, kt + 1, H == 0 ? 0 : 1);
+        });
+        if (HAS_NEXT && (SEG2 || MASK)) { asm volatile("s_nop 15\n\ts_nop 7" ::: "memory"); mask_half(sc[QB1], H == 0 ? kt : kt + 1, H == 0 ? 1 : 0); }
+    };
+#undef A3_I
+#undef A3_FENCE
+
     f32x16 sa[QB];   // the score blocks of the half tile about to be consumed
     Frags fa, fb;
     const int h_first = (BAL && role == 2) ? 1 : 0;   // the half of tile 0 this wave starts with
@@ -422,7 +538,23 @@ static __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
     using F_ = std::false_type;
     using H0 = std::integral_constant<int, 0>;
     using H1 = std::integral_constant<int, 1>;
-    if (A3_ABL & 16) {   // (ablation: no KV loop at all -- launch + prologue + epilogue)
+    if (Q2) {
+        q2_softmax(sa[0], p0);   // block 0 of the first half: its probabilities enter the loop converted
+        int kt = 0;
+        for (; kt + 2 < nkt; kt++) {
+            q2_step(sa, kt, fa, H0{}, T_{}, F_{});
+            q2_step(sa, kt, fa, H1{}, T_{}, F_{});
+        }
+        for (; kt < nkt; kt++) {
+            if (kt + 1 < nkt) {
+                q2_step(sa, kt, fa, H0{}, T_{}, T_{});
+                q2_step(sa, kt, fa, H1{}, T_{}, T_{});
+            } else {
+                q2_step(sa, kt, fa, H0{}, F_{}, T_{});
+                q2_step(sa, kt, fa, H1{}, F_{}, F_{});
+            }
+        }
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last asm MFMAs' results (O, row sums) are read by compiler-scheduled code next
     } else if (!BAL || role == 0) {
         int kt = 0;
         for (; kt + 2 < nkt; kt++) {   // tiles whose successors are complete tiles: no masks
