@@ -204,8 +204,9 @@ static __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
         st_prev = t_;                                                                                \
     }
     const int nkt = nkt1 + (SEG2 ? (kv2_len + 63) >> 6 : 0);
+    constexpr bool PAIR = true;   // one ring step per TWO tiles (see ring_step)
 #pragma unroll
-    for (int t = 0; t < (NST >= 9 ? NST : NST - 1); t++)
+    for (int t = 0; t < (PAIR ? NST : NST - 1); t++)
         if (t < nkt) issue_tile(t);
 
     // The unit of the inner loop is a HALF tile: 32 keys = one 32 x 32 score block per query block (16 registers; two whole 64-key score
@@ -250,10 +251,11 @@ static __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
         return fmaxf(m, __shfl_xor(m, 32, 64));
     };
     // ring step kt: tile kt + 1 landed (its K feeds the next score block); every wave is past tile kt - 1, so stage (kt - 1) % NST is free.
-    // PAIR (the 9-stage ring of a lone workgroup): one step per TWO tiles -- at even kt tiles kt + 1 and kt + 2 are made visible and the
-    // stages of tiles kt - 2 and kt - 1 refilled; half the barriers (38 % of the wave cycles at C2 were parked at s_waitcnt / s_barrier:
-    // profiles/r02_pmc_attention_sq.txt).  The prologue fills the whole ring and makes tiles 0-2 visible.
-    constexpr bool PAIR = NST >= 9;
+    // PAIR: one step per TWO tiles -- at even kt tiles kt + 1 and kt + 2 are made visible and the stages of tiles kt - 2 and kt - 1 refilled;
+    // half the barriers (38 % of the wave cycles at C2 were parked at s_waitcnt / s_barrier: profiles/r02_pmc_attention_sq.txt).  The prologue
+    // fills the whole ring and makes tiles 0-2 visible.  Three resident tiles + two being refilled: five stages are enough, so the 5-stage ring
+    // of the batch shapes (two workgroups per CU) steps in pairs too since round 3 (the ring step was 17-18 % of the loop there:
+    // profiles/r03_attn_ablate.txt); a refill then has two tile times to land instead of three.
     auto ring_step = [&](int kt) {
         if (PAIR) {
             if ((kt & 1) || kt == 0) return;
