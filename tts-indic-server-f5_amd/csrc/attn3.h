@@ -69,14 +69,16 @@ static __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
     // Workgroup -> (query tile, head, sequence), XCD-aware: the hardware deals consecutive workgroup ids round-robin to the 8 XCDs, which would
     // put the query tiles of one (sequence, head) -- the workgroups that read the same K / V^T rows -- on 8 different L2s, each of them pulling
     // every row from beyond L2.  Re-number so that an XCD gets a contiguous run of (sequence, head, tile) triples, tile fastest.
-    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    // Round 3: inside an XCD's run the HEAD is the slowest index and the sequence the middle one (it used to be the other way round: an XCD
+    // then owned whole sequences, and in a ragged batch the XCD with the longest ones finished last -- 16 sequences of 900..1890 frames: 4x the
+    // work on one XCD than on another: 275 us against 212 now).  An XCD now takes a group of heads of EVERY sequence: equal work whatever
+    // the lengths.  (Walking the sequences by decreasing cost on top of that measured no different: profiles/r03_attn_ragged_mapping.txt.)
+    int bx, by, bz;
     {
-        const unsigned gx = gridDim.x, gy = gridDim.y, total = gx * gy * gridDim.z, per = total >> 3;
-        const unsigned lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
-        if (lin < per * 8) {
-            const unsigned v = (lin & 7) * per + (lin >> 3);
-            bx = (int)(v % gx); by = (int)((v / gx) % gy); bz = (int)(v / (gx * gy));
-        }
+        const unsigned gx = gridDim.x, gz = gridDim.z, total = gx * gridDim.y * gz, per = total >> 3;
+        const unsigned lin = blockIdx.x + gx * (blockIdx.y + gridDim.y * blockIdx.z);
+        const unsigned v = lin < per * 8 ? (lin & 7) * per + (lin >> 3) : lin;
+        bx = (int)(v % gx); bz = (int)((v / gx) % gz); by = (int)(v / (gx * gz));
     }
     const int seq = bz, head = by;
     const int len = p.seq_len[seq], kvlen = p.seq_kvlen[seq], row0 = p.seq_row0[seq];
