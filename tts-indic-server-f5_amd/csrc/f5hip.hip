@@ -395,7 +395,7 @@ static int ensure_workspace(f5hip_dit* m, int rows_pad, int frames, int n_seq) {
         m->xs = a.plane2(R * 128); m->tn = a.plane2(R * Td); m->tg = a.plane2(R * 2 * Td); m->act = a.plane2(R * (128 + m->td_pad));
         m->sinp = a.plane2(128 * 256); m->t1 = a.plane2((size_t)128 * D); m->st = a.plane2((size_t)128 * D);
         m->skipbuf.resize(m->arch == 1 ? c.depth / 2 : 0);
-        for (auto& sb : m->skipbuf) sb = a.plane2(R * D);
+        for (auto& sb : m->skipbuf) sb = a.plane2(R * 2 * D);   // [R][2 D]: the concatenated operand [x || skip] of the U-skip Linear, built in place
         // qk: +256 rows because the last 256-query tile of attn2 may read (never store) past the padded rows
         m->qk = a.bf16((R + 256) * 2 * D); m->vt = a.bf16((size_t)D * R);
         if (!pass) {
@@ -853,21 +853,20 @@ static int forward_unett_layers(f5hip_dit* m, int ti, int n_blocks, hipStream_t 
     for (int l = 0; l < nb; l++) {
         if (l < c.depth / 2) {
             prof_begin(PROF_OTHER, st);
-            if (m->skip_f16) hipLaunchKernelGGL(cast_rows_f16_kernel, dim3(M), dim3(256), 0, st, m->h, D, D, M, m->skipbuf[l].hi, D, 0);
-            else hipLaunchKernelGGL(split_rows_kernel, dim3(M), dim3(256), 0, st, m->h, D, D, M, (const int*)nullptr, m->skipbuf[l].hi, m->skipbuf[l].lo, D, 0);
+            // the skip is saved where its consumer wants it: columns D .. 2 D - 1 of that layer's [x || skip] operand (round 3: it used to go to a
+            // [M][D] buffer and was copied behind x with hipMemcpy2DAsync at the consumer, ~55 % of the "other" kernel class at C5)
+            if (m->skip_f16) hipLaunchKernelGGL(cast_rows_f16_kernel, dim3(M), dim3(256), 0, st, m->h, D, D, M, m->skipbuf[l].hi, 2 * D, D);
+            else hipLaunchKernelGGL(split_rows_kernel, dim3(M), dim3(256), 0, st, m->h, D, D, M, (const int*)nullptr, m->skipbuf[l].hi, m->skipbuf[l].lo, 2 * D, D);
             prof_end(PROF_OTHER, st);
             CKL("skip save");
         } else {
             const Plane2& sk = m->skipbuf[c.depth - 1 - l];
             prof_begin(PROF_OTHER, st);
-            if (m->skip_f16) hipLaunchKernelGGL(cast_rows_f16_kernel, dim3(M), dim3(256), 0, st, m->h, D, D, M, m->ff.hi, 2 * D, 0);
-            else hipLaunchKernelGGL(split_rows_kernel, dim3(M), dim3(256), 0, st, m->h, D, D, M, (const int*)nullptr, m->ff.hi, m->ff.lo, 2 * D, 0);
-            CKL("skip concat x");
-            if (hipMemcpy2DAsync(m->ff.hi + D, (size_t)2 * D * 2, sk.hi, (size_t)D * 2, (size_t)D * 2, M, hipMemcpyDeviceToDevice, st) != hipSuccess ||
-                (!m->skip_f16 && hipMemcpy2DAsync(m->ff.lo + D, (size_t)2 * D * 2, sk.lo, (size_t)D * 2, (size_t)D * 2, M, hipMemcpyDeviceToDevice, st) != hipSuccess))
-                return fail(-6, "skip concat copy");
+            if (m->skip_f16) hipLaunchKernelGGL(cast_rows_f16_kernel, dim3(M), dim3(256), 0, st, m->h, D, D, M, sk.hi, 2 * D, 0);
+            else hipLaunchKernelGGL(split_rows_kernel, dim3(M), dim3(256), 0, st, m->h, D, D, M, (const int*)nullptr, sk.hi, sk.lo, 2 * D, 0);
             prof_end(PROF_OTHER, st);
-            GemmArgs sp = gemm_base(m->ff, 2 * D, m->wskip[l], M);
+            CKL("skip concat x");
+            GemmArgs sp = gemm_base(sk, 2 * D, m->wskip[l], M);
             sp.bias = nullptr; sp.out_f32 = m->h; sp.ldo = D;
             CK(run_gemm(m, sp, m->wskip[l], EPI_GENERIC, false, 64, st));
         }
