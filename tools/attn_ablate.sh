@@ -1,6 +1,6 @@
 #!/bin/bash
 # Timing ablations of attn3's hot loop (diagnostics; the results are WRONG numerically): one library per A3_ABL value (attn3.h: bit 0 no ring
-# step, bit 1 exp2 -> v_mul, bit 2 no LDS fragment reads, bit 3 no P V / row-sum MFMAs, bit 4 no KV loop), each = the production objects with tu_attn.hip
+# step, bit 1 exp2 -> v_mul, bit 2 no LDS fragment reads, bit 3 no P V / row-sum MFMAs, bit 4 no KV loop, bit 5 the launch alone), each = the production objects with tu_attn.hip
 # recompiled.  Build here (no GPU needed), then on the GPU box:
 #   for n in 1 2 4 8 5 7 15; do F5HIP_LIB=$PWD/tts-indic-server-f5_amd/csrc/abl/libf5hip_abl$n.so F5HIP_TORCH_OPS=0 ATTN_AB_SHAPES=0,1,4 python tools/attn_ab.py; done
 # Result of round 3: profiles/r03_attn_ablate.txt.

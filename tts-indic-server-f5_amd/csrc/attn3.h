@@ -51,7 +51,7 @@
 #ifndef A3_ABL
 // timing ablations of the hot loop (WRONG results, diagnostics only; tools/attn_ablate.sh builds one library per value and profiles/r03_attn_ablate.txt
 // holds the result): bit 0 no ring step (no wait / barrier / refill), bit 1 exp2 -> v_mul, bit 2 no LDS fragment reads, bit 3 no P V / row-sum MFMAs,
-// bit 4 no KV loop at all (launch + prologue + epilogue)
+// bit 4 no KV loop at all (launch + prologue + epilogue), bit 5 return behind the sequence meta loads (the launch alone)
 #define A3_ABL 0
 #endif
 #define A3_P_LIMIT 0x1p15f
@@ -86,6 +86,7 @@ static __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
     const int nkt1 = (kvlen + 63) >> 6;
     const int q0 = bx * QT;
     if (q0 >= len) return;
+    if (A3_ABL & 32) return;   // (ablation: the launch alone -- dispatch with this kernel's LDS / register footprint, kernarg + sequence meta loads)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 31, fh = lane >> 5;
