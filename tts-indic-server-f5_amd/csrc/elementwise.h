@@ -17,6 +17,18 @@ __global__ __launch_bounds__(256) void ln_kernel(const LnArgs p) {
     ln_row<NV>(p, b * 4 + (threadIdx.x >> 6), threadIdx.x & 63);
 }
 
+// Rotary factors per ROW: out_cos / out_sin [R][32] = table[row_pos[r]][32].  Once per sampler call (the positions do not change over the ODE steps):
+// the QKV epilogues then fetch a row's factors with one load instead of two dependent ones (row_pos, then the table) -- the 32 rotary tiles of the C2
+// launch finished 2.7 us behind the other 224.
+__global__ __launch_bounds__(256) void rope_rows_kernel(const int* row_pos, const float* rope_cos, const float* rope_sin, int R, int max_pos, float* out_cos, float* out_sin) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= R * 32) return;
+    const int r = i >> 5, j = i & 31;
+    const int pos = min(max(row_pos[r], 0), max_pos - 1);
+    out_cos[i] = rope_cos[pos * 32 + j];
+    out_sin[i] = rope_sin[pos * 32 + j];
+}
+
 // ------------------------------------------------------------------------------------------------
 // GRN (F/model/modules.py:231-234): Gx[c] = ||y[:, c]||_2 over the frames of one sequence.
 __global__ __launch_bounds__(256) void grn_stats_kernel(const float* y, int ldy, int C, const int* seq_row0,

@@ -63,6 +63,8 @@ struct f5hip_dit {
     float *g_out = nullptr, *zeros = nullptr;
     std::vector<TextBlock> tblk;
     float *text_emb = nullptr, *text_pos = nullptr, *rope_cos = nullptr, *rope_sin = nullptr;
+    float *rope_row_cos = nullptr, *rope_row_sin = nullptr;   // [rows][32]: the rotary factors of every row of the current layout (workspace; rope_rows_kernel)
+    int rope_max_pos = 0;
     int arch = 0;     // 0 = DiT (F5-TTS), 1 = UNetT (E2-TTS): one extra row per sequence carries the time token, 2 = MMDiT: the text tokens of
                       // every sequence are rows of their own stream, laid out behind all audio rows (rows [M, M + Mc))
     int td_pad = 0;   // text_dim rounded up to 32 (K padding of the step-invariant input-projection operand)
@@ -390,6 +392,7 @@ static int ensure_workspace(f5hip_dit* m, int rows_pad, int frames, int n_seq) {
         a.reset(pass ? (char*)m->ws.ptr : nullptr);
         m->h = a.f32(R * D); m->h0 = a.f32(R * D); m->ce = a.f32(R * D); m->pred = a.f32(R * 128);
         m->te = a.f32(R * Td); m->ty = a.f32(R * 2 * Td); m->gx = a.f32(S * 2 * Td);
+        m->rope_row_cos = a.f32(R * 32); m->rope_row_sin = a.f32(R * 32);
         m->mod = a.f32((size_t)128 * m->n_adaln + 64); m->xstate = a.f32(U * c.mel_dim); m->xmid = a.f32(U * c.mel_dim); m->temb = a.f32((size_t)128 * D);
         m->hn = a.plane2(R * D + 256); m->c1 = a.plane2(R * D + 256); m->ao = a.plane2(R * D); m->ff = a.plane2(R * F);
         m->xs = a.plane2(R * 128); m->tn = a.plane2(R * Td); m->tg = a.plane2(R * 2 * Td); m->act = a.plane2(R * (128 + m->td_pad));
@@ -498,6 +501,9 @@ static int setup_sequences(f5hip_dit* m, const std::vector<SeqDesc>& seqs, int n
     m->d_urow_c = d; m->d_urow_u = d + U; m->d_frame_is_cond = d + 2 * U;
     d += 3 * U;
     m->d_j_row0 = d; m->d_j_len = d + 2 * S; m->d_j_kvlen = d + 4 * S; m->d_j_kv_row0 = d + 6 * S; m->d_j_kv2_row0 = d + 8 * S; m->d_j_kv2_len = d + 10 * S;
+    // rotary factors per row of this layout (one load in the QKV epilogues instead of row_pos -> table)
+    hipLaunchKernelGGL(rope_rows_kernel, dim3((R * 32 + 255) / 256), dim3(256), 0, st, m->d_row_pos, m->rope_cos, m->rope_sin, R, 4097, m->rope_row_cos, m->rope_row_sin);
+    if (hipGetLastError() != hipSuccess) return fail(-7, "rope_rows_kernel launch");
     m->M = rows_x; m->M_pad = rows_x; m->Mc = R - rows_x; m->Rtot = R; m->n_seq = S; m->n_frames = U;
     return 0;
 }
@@ -807,6 +813,14 @@ static int precompute_time(f5hip_dit* m, const float* t_host, int n_t, hipStream
     return r;
 }
 
+// rotary operands of a QKV launch over rows row_off ..: the per-row tables of the current layout (one load per row in the epilogue);
+// F5HIP_ROPE_ROWS=0: positions + the [pos][32] tables (two dependent loads; A/B)
+static void set_rope(GemmArgs& q, const f5hip_dit* m, int row_off) {
+    static const bool per_row = !(getenv("F5HIP_ROPE_ROWS") && atoi(getenv("F5HIP_ROPE_ROWS")) == 0);
+    if (per_row) { q.row_pos = nullptr; q.rope_cos = m->rope_row_cos + (size_t)row_off * 32; q.rope_sin = m->rope_row_sin + (size_t)row_off * 32; }
+    else { q.row_pos = m->d_row_pos + row_off; q.rope_cos = m->rope_cos; q.rope_sin = m->rope_sin; }
+}
+
 static int launch_attention(f5hip_dit* m, hipStream_t st) {
     const f5hip_dit_config& c = m->cfg;
     AttnArgs at; memset(&at, 0, sizeof(at));
@@ -873,7 +887,7 @@ static int forward_unett_layers(f5hip_dit* m, int ti, int n_blocks, hipStream_t 
         ln.scale = m->g_attn[l];
         ln.f16_out = m->blk_f16 ? 1 : 0;   // block norms feed the fp16 block GEMMs in mixed mode; the final norm (proj_out) stays split bf16
         GemmArgs q = gemm_base(m->hn, D, m->wqkv[l], M);
-        q.D = D; q.row_pos = m->d_row_pos; q.rope_cos = m->rope_cos; q.rope_sin = m->rope_sin; q.qk = m->qk; q.vt = m->vt; q.ldvt = m->Rtot;
+        q.D = D; set_rope(q, m, 0); q.qk = m->qk; q.vt = m->vt; q.ldvt = m->Rtot;
         CK(run_ln(ln, st));
         CK(run_gemm(m, q, m->wqkv[l], EPI_QKV, false, 128, st));
         CK(launch_attention(m, st));
@@ -967,10 +981,10 @@ static int forward_mmdit_layers(f5hip_dit* m, int ti, int n_blocks, hipStream_t 
         CK(run_ln(last ? ln_for(true, mc + D, mc, m->blk_f16) : ln_for(true, mc, mc + D, m->blk_f16), st));
         CK(run_ln(ln_for(false, mx, mx + D, m->blk_f16), st));
         GemmArgs q = gemm_base(m->hn, D, m->wqkv[l], M);
-        q.D = D; q.row_pos = m->d_row_pos; q.rope_cos = m->rope_cos; q.rope_sin = m->rope_sin; q.qk = m->qk; q.vt = m->vt; q.ldvt = m->Rtot;
+        q.D = D; set_rope(q, m, 0); q.qk = m->qk; q.vt = m->vt; q.ldvt = m->Rtot;
         CK(run_gemm(m, q, m->wqkv[l], EPI_QKV, false, 128, st, M));
         GemmArgs qc = gemm_base(hn_c, D, m->wqkv_c[l], Mc);
-        qc.D = D; qc.row_pos = m->d_row_pos + ro; qc.rope_cos = m->rope_cos; qc.rope_sin = m->rope_sin;
+        qc.D = D; set_rope(qc, m, ro);
         qc.qk = m->qk + ro * 2 * D; qc.vt = m->vt + ro; qc.ldvt = m->Rtot;
         CK(run_gemm(m, qc, m->wqkv_c[l], EPI_QKV, false, 128, st, Mc));
         CK(launch_attention(m, st));
@@ -1059,7 +1073,7 @@ static int forward_step(f5hip_dit* m, int ti, int n_blocks, hipStream_t st) {
     for (int l = 0; l < nb; l++) {
         const float* ml = mod + (size_t)l * 6 * D;   // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
         GemmArgs q = gemm_base(m->hn, D, m->wqkv[l], M);
-        q.D = D; q.row_pos = m->d_row_pos; q.rope_cos = m->rope_cos; q.rope_sin = m->rope_sin; q.qk = m->qk; q.vt = m->vt; q.ldvt = m->Rtot;
+        q.D = D; set_rope(q, m, 0); q.qk = m->qk; q.vt = m->vt; q.ldvt = m->Rtot;
         CK(run_gemm(m, q, m->wqkv[l], EPI_QKV, false, 128, st));
         static const int dump_qkv = getenv("F5HIP_DUMP_QKV") ? atoi(getenv("F5HIP_DUMP_QKV")) : -1;   // diagnostics, read once
         if (dump_qkv >= 0 && l == dump_qkv / 100 && ti == dump_qkv % 100) debug_dump_qkv(m, st);

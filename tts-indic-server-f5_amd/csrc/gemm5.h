@@ -399,7 +399,7 @@ F5_DEVICE void g5_qk_rows(const GemmArgs& p, const float* slab, int m0, int n0, 
 #pragma unroll
         for (int t = 0; t < NT; t++) {
             const int row = m0 + (wave + 8 * t) * 4 + r_in;
-            const int pos = (wave + 8 * t < NG && row < p.M) ? p.row_pos[row] : 0;
+            const int pos = (wave + 8 * t < NG && row < p.M) ? (p.row_pos ? p.row_pos[row] : row) : 0;   // (row_pos == null: the tables are per ROW, GemmArgs::rope_cos)
             cs[t] = *reinterpret_cast<const float2*>(p.rope_cos + pos * 32 + (c4 >> 1));
             sn[t] = *reinterpret_cast<const float2*>(p.rope_sin + pos * 32 + (c4 >> 1));
         }

@@ -332,7 +332,7 @@ F5_DEVICE void g6_qk_direct(const GemmArgs& p, f32x4 (&acc)[RBW][4], int n0, int
         const bool rok = row < m_end;
         float2 cs[4], sn[4];
         if (rot) {
-            const int pos = rok ? p.row_pos[row] : 0;
+            const int pos = rok ? (p.row_pos ? p.row_pos[row] : row) : 0;   // (row_pos == null: per-row tables)
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 cs[j] = *reinterpret_cast<const float2*>(p.rope_cos + pos * 32 + j * 8 + fq * 2);

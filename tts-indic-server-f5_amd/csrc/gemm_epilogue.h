@@ -61,7 +61,7 @@ struct GemmArgs {
     int f16_out;          // 1: out_hi receives ONE fp16 plane (A operand of a PREC_F16 GEMM); only for the (no residual, no fp32 output) epilogues
     // QKV epilogue
     int D;                   // model dim (N == 3 D)
-    const int* row_pos;      // [M_pad] frame index inside the row's sequence
+    const int* row_pos;      // [M_pad] frame index inside the row's sequence, or null: rope_cos / rope_sin are per ROW ([M_pad][32], gathered once per call)
     const float* rope_cos;   // [max_pos][32]
     const float* rope_sin;
     __bf16* qk;              // [M_pad][2 D]  fp16 bits (attention operands are fp16: attn3.h)
@@ -188,7 +188,7 @@ F5_DEVICE void epi_qk_rows_t(const GemmArgs& p, const float* stg, int m_base, in
         cs[q] = make_float2(1.f, 1.f);
         sn[q] = make_float2(0.f, 0.f);
         if (ROT && nd < 64) {   // (a wave tile wider than one head -- WN = 128 -- rotates only its lanes inside head 0)
-            const int pos = p.row_pos[m_base + q * RPP + r0];
+            const int pos = p.row_pos ? p.row_pos[m_base + q * RPP + r0] : m_base + q * RPP + r0;   // (row_pos == null: per-row tables)
             cs[q] = *reinterpret_cast<const float2*>(p.rope_cos + pos * 32 + (nd >> 1));
             sn[q] = *reinterpret_cast<const float2*>(p.rope_sin + pos * 32 + (nd >> 1));
         }
