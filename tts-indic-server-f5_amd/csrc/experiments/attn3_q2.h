@@ -388,7 +388,7 @@ static __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
     };
 
     // ---- Q2 (QB = 2 at two waves per SIMD, NST = 5): 64 queries per wave, so every K / V^T fragment read from LDS feeds TWO MFMAs -- the LDS
-    // pipe was the co-bottleneck of the 32-query wave (one 1 KiB fragment read per 32-clock MFMA is exactly the CU's 128 B / clk; ablations in
+    // pipe was the co-bottleneck of the 32-query wave (the premise was wrong -- CDNA4's LDS is 256 B / clk and the array 21 % busy, profiles/r03_pmc_attention_lds.txt; ablations in
     // profiles/r03_attn_ablate.txt: no LDS reads -12..14 %, exp2 -> v_mul only -3 %).  256 registers hold ONE fragment set and no spare score
     // block, so a half-tile step is two regions that pipeline the two query blocks against each other inside the wave:
     //   region 1: MFMAs of block 0 (next scores -> sc[0], O[0] += V P0, row sums)  ||  exp2 / convert of block 1 (sc[1] -> p1)
@@ -474,7 +474,7 @@ static __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(
         A3_FENCE();
     };
     // Q2 (QB = 2: 64 queries per wave, one wave per SIMD): every K / V^T fragment read from LDS feeds TWO MFMAs -- the LDS pipe was the
-    // co-bottleneck of the 32-query wave (one 1 KiB fragment per 32-clock MFMA is exactly the CU's 128 B / clk; profiles/r03_attn_ablate.txt:
+    // co-bottleneck of the 32-query wave (premise wrong: the LDS array is 21 % busy, profiles/r03_pmc_attention_lds.txt; profiles/r03_attn_ablate.txt:
     // no LDS reads -12..14 %, exp2 -> v_mul only -3 %).  A half-tile step is two regions that pipeline the two query blocks against each
     // other inside the wave: region 1 = MFMAs of block 0 || softmax of block 1, region 2 = MFMAs of block 1 || softmax of block 0's NEW scores.
     // p0 (the converted probabilities of block 0) crosses the step boundary.
